@@ -1,0 +1,693 @@
+/*
+ * oracle/gm_oracle.c -- CPU restatement of GraphMaker's reverse-diffusion denoising step.
+ *
+ * TEST INFRASTRUCTURE ONLY (see gm_oracle.h).  Build: oracle/Makefile -> oracle/libgm_oracle.so
+ * Compile with -ffp-contract=off: every fused multiply-add below is an explicit fmaf(), every other
+ * a*b+c is two roundings, so the arithmetic is exactly what the comments say.
+ *
+ * Floating-point orders are chosen so that the HIP library (f32 MFMA = k-ordered fmaf chains,
+ * wave-level butterfly reductions) can reproduce the oracle bit for bit; against the reference
+ * (torch fp32, BLAS orderings unknown) results agree within fp32 tolerance (tests/test_oracle_golden.py).
+ */
+#include "gm_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define GMO_VERSION 0x00010000u
+
+uint32_t gmo_version(void) { return GMO_VERSION; }
+
+void gmo_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+int gmo_get_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------ RNG */
+/* Philox4x32-10 (Salmon et al., SC'11), the generator torch's device RNG also uses.  The reference draws
+ * with torch.multinomial (model/diffusion.py:202,228,421,833); shared-RNG parity replaces those draws by
+ * thresholding uniforms, and this is where the uniforms come from. */
+void gmo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+float gmo_u01(uint32_t word) { return (float)(word >> 8) * 5.9604644775390625e-08f; /* 2^-24 */ }
+
+static inline float philox_u(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, int w) {
+    uint32_t ctr[4] = {c0, c1, c2, c3};
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t out[4];
+    gmo_philox4x32_10(ctr, key, out);
+    return gmo_u01(out[w]);
+}
+static inline float u_Y(uint64_t seed, int64_t v) {
+    return philox_u(seed, (uint32_t)(v >> 2), 0u, 0u, GMO_STREAM_Y, (int)(v & 3));
+}
+static inline float u_idx64(uint64_t seed, uint32_t step, uint32_t stream, uint64_t idx) {
+    uint64_t q = idx >> 2;
+    return philox_u(seed, (uint32_t)q, (uint32_t)(q >> 32), step, stream, (int)(idx & 3));
+}
+static inline float u_E(uint64_t seed, uint32_t step, int64_t i, int64_t j) {
+    return philox_u(seed, (uint32_t)(j >> 2), (uint32_t)i, step, GMO_STREAM_E, (int)(j & 3));
+}
+static inline int64_t pair_rank(int64_t n, int64_t i, int64_t j) { /* torch.triu_indices(n,n,offset=1) order */
+    return i * (2 * n - i - 1) / 2 + (j - i - 1);
+}
+
+void gmo_fill_uniform_Y(uint64_t seed, int64_t n, float* u) {
+    for (int64_t v = 0; v < n; ++v) u[v] = u_Y(seed, v);
+}
+void gmo_fill_uniform_X(uint64_t seed, uint32_t step, int64_t n, int64_t F, float* u) {
+#pragma omp parallel for schedule(static)
+    for (int64_t idx = 0; idx < n * F; ++idx) u[idx] = u_idx64(seed, step, GMO_STREAM_X, (uint64_t)idx);
+}
+void gmo_fill_uniform_E_prior(uint64_t seed, int64_t n, float* u) {
+#pragma omp parallel for schedule(static)
+    for (int64_t idx = 0; idx < n * n; ++idx) u[idx] = u_idx64(seed, 0u, GMO_STREAM_E_PRIOR, (uint64_t)idx);
+}
+void gmo_fill_uniform_E(uint64_t seed, uint32_t step, int64_t n, float* u) {
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = i + 1; j < n; ++j) u[pair_rank(n, i, j)] = u_E(seed, step, i, j);
+}
+
+/* ------------------------------------------------------------------ schedule / transitions */
+/* model/diffusion.py:96-118 NoiseSchedule.__init__ : cosine schedule in float64, then fp32 log/cumsum/exp */
+void gmo_noise_schedule(int T, float* betas, float* alphas, float* alpha_bars) {
+    int num_steps = T + 2;
+    double* ab = (double*)malloc(sizeof(double) * (size_t)num_steps);
+    double step = (double)num_steps / (double)(num_steps - 1); /* np.linspace(0, num_steps, num_steps) */
+    const double s = 0.008;
+    for (int k = 0; k < num_steps; ++k) {
+        double t = (k == num_steps - 1) ? (double)num_steps : (double)k * step;
+        double c = cos(0.5 * M_PI * ((t / num_steps) + s) / (1 + s));
+        ab[k] = c * c;
+    }
+    double ab0 = ab[0];
+    for (int k = 0; k < num_steps; ++k) ab[k] /= ab0;
+    float logsum = 0.0f;
+    for (int k = 0; k <= T; ++k) {
+        double a = ab[k + 1] / ab[k];
+        float b = (float)(1.0 - a);
+        betas[k] = b;
+        float bc = b < 0.0f ? 0.0f : (b > 0.9999f ? 0.9999f : b);
+        alphas[k] = 1.0f - bc;
+        logsum = logsum + logf(alphas[k]);
+        alpha_bars[k] = expf(logsum);
+    }
+    free(ab);
+}
+
+/* model/diffusion.py:52-84 get_Q_bar_E / get_Q_bar_X :  Q = a*I + (1-a)*m  with rows of m = marginal */
+void gmo_transition(float a, float m0, float m1, float Q[4]) {
+    float na = 1.0f - a;
+    float m[2] = {m0, m1};
+    for (int r = 0; r < 2; ++r)
+        for (int c = 0; c < 2; ++c) {
+            float eye = (r == c) ? 1.0f : 0.0f;
+            float t0 = a * eye;
+            float t1 = na * m[c];
+            Q[r * 2 + c] = t0 + t1;
+        }
+}
+
+/* model/diffusion.py:351-406 BaseModel.posterior for a one-hot Z_t = e:
+ *   out[i][k] = (Q_t[k][e] * Qbar_s[i][k]) / Qbar_t[i][e]   (denominator 0 -> 1, :397)
+ *   prob[k]   = prior[0]*out[0][k] + prior[1]*out[1][k]
+ * The table holds out[i][k] for both e:  tab[(i*2+k)*2+e]. */
+void gmo_posterior_table(const float Qt[4], const float Qbs[4], const float Qbt[4], float tab[8]) {
+    for (int i = 0; i < 2; ++i)
+        for (int k = 0; k < 2; ++k)
+            for (int e = 0; e < 2; ++e) {
+                float num = Qt[k * 2 + e] * Qbs[i * 2 + k];
+                float den = Qbt[i * 2 + e];
+                if (den == 0.0f) den = 1.0f;
+                tab[(i * 2 + k) * 2 + e] = num / den;
+            }
+}
+
+void gmo_posterior_tables_X(int64_t F, const float* X_marginal, float alpha_t, float abar_s, float abar_t,
+                            float* tab) {
+    for (int64_t f = 0; f < F; ++f) {
+        float Qt[4], Qbs[4], Qbt[4];
+        gmo_transition(alpha_t, X_marginal[2 * f], X_marginal[2 * f + 1], Qt);
+        gmo_transition(abar_s, X_marginal[2 * f], X_marginal[2 * f + 1], Qbs);
+        gmo_transition(abar_t, X_marginal[2 * f], X_marginal[2 * f + 1], Qbt);
+        gmo_posterior_table(Qt, Qbs, Qbt, tab + 8 * f);
+    }
+}
+
+void gmo_posterior_apply(const float tab[8], int z_t, float prior0, float prior1, float* p0, float* p1) {
+    float a0 = prior0 * tab[(0 * 2 + 0) * 2 + z_t];
+    float b0 = prior1 * tab[(1 * 2 + 0) * 2 + z_t];
+    float a1 = prior0 * tab[(0 * 2 + 1) * 2 + z_t];
+    float b1 = prior1 * tab[(1 * 2 + 1) * 2 + z_t];
+    *p0 = a0 + b0;
+    *p1 = a1 + b1;
+}
+
+static inline int draw2(float u, float p0, float p1) {
+    float s = p0 + p1;
+    float us = u * s;
+    return us < p1 ? 1 : 0;
+}
+
+/* exp for x <= 0, shared bit for bit with the HIP library (Cephes-style expf; ~1 ulp). */
+static inline float gm_expf_nonpos(float x) {
+    if (x < -80.0f) x = -80.0f;
+    float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693359375f, x);
+    r = fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    float r2 = r * r;
+    float y = fmaf(p, r2, r) + 1.0f;
+    return ldexpf(y, (int)n);
+}
+
+/* softmax over 2 classes (model/diffusion.py:457, :879) */
+void gmo_softmax2(float l0, float l1, float* p0, float* p1) {
+    float m = l0 > l1 ? l0 : l1;
+    float e0 = gm_expf_nonpos(l0 - m);
+    float e1 = gm_expf_nonpos(l1 - m);
+    float s = e0 + e1;
+    *p0 = e0 / s;
+    *p1 = e1 / s;
+}
+
+/* ------------------------------------------------------------------ priors */
+/* model/diffusion.py:831-833  Y_0 ~ Cat(Y_marginal) */
+void gmo_prior_Y(int64_t n, int C, const float* Y_marginal, const float* u_or_null, uint64_t seed, int32_t* y) {
+    float sum = 0.0f;
+    for (int c = 0; c < C; ++c) sum = sum + Y_marginal[c];
+    for (int64_t v = 0; v < n; ++v) {
+        float u = u_or_null ? u_or_null[v] : u_Y(seed, v);
+        float us = u * sum;
+        float cum = 0.0f;
+        int pick = C - 1;
+        for (int c = 0; c < C; ++c) {
+            cum = cum + Y_marginal[c];
+            if (us < cum) { pick = c; break; }
+        }
+        y[v] = pick;
+    }
+}
+
+/* model/diffusion.py:842-844 + 214-237  X_T[v][f] ~ Bernoulli(X_marginal[f]) ; draw index f*n+v */
+void gmo_prior_X(int64_t n, int64_t F, const float* X_marginal, const float* u_or_null, uint64_t seed,
+                 uint8_t* x) {
+#pragma omp parallel for schedule(static)
+    for (int64_t v = 0; v < n; ++v)
+        for (int64_t f = 0; f < F; ++f) {
+            int64_t idx = f * n + v;
+            float u = u_or_null ? u_or_null[idx] : u_idx64(seed, 0u, GMO_STREAM_X, (uint64_t)idx);
+            x[v * F + f] = (uint8_t)draw2(u, X_marginal[2 * f], X_marginal[2 * f + 1]);
+        }
+}
+
+/* model/diffusion.py:836-839 + 188-212  N^2 draws, upper triangle INCLUDING the diagonal mirrored down */
+void gmo_prior_E(int64_t n, int64_t wpr, float p0, float p1, const float* u_or_null, uint64_t seed,
+                 uint32_t* bits) {
+    memset(bits, 0, sizeof(uint32_t) * (size_t)(n * wpr));
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = i; j < n; ++j) {
+            int64_t idx = i * n + j;
+            float u = u_or_null ? u_or_null[idx] : u_idx64(seed, 0u, GMO_STREAM_E_PRIOR, (uint64_t)idx);
+            if (draw2(u, p0, p1)) {
+                bits[i * wpr + (j >> 5)] |= 1u << (j & 31);
+                bits[j * wpr + (i >> 5)] |= 1u << (i & 31);
+            }
+        }
+}
+
+/* ------------------------------------------------------------------ adjacency */
+void gmo_bitmap_from_dense_i64(int64_t n, int64_t wpr, const int64_t* dense, uint32_t* bits) {
+    memset(bits, 0, sizeof(uint32_t) * (size_t)(n * wpr));
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = 0; j < n; ++j)
+            if (dense[i * n + j] != 0) bits[i * wpr + (j >> 5)] |= 1u << (j & 31);
+}
+void gmo_dense_i64_from_bitmap(int64_t n, int64_t wpr, const uint32_t* bits, int64_t* dense) {
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = 0; j < n; ++j) dense[i * n + j] = (bits[i * wpr + (j >> 5)] >> (j & 31)) & 1u;
+}
+/* model/diffusion.py:422-424  E[dst,src] = E[src,dst] = draw : mirror the strict upper triangle */
+void gmo_symmetrize_upper(int64_t n, int64_t wpr, const uint32_t* upper, uint32_t* sym) {
+    memset(sym, 0, sizeof(uint32_t) * (size_t)(n * wpr));
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = i + 1; j < n; ++j)
+            if ((upper[i * wpr + (j >> 5)] >> (j & 31)) & 1u) {
+                sym[i * wpr + (j >> 5)] |= 1u << (j & 31);
+                sym[j * wpr + (i >> 5)] |= 1u << (i & 31);
+            }
+}
+/* model/diffusion.py:252-256 get_adj : E_t.nonzero() is row-major sorted -> CSR with ascending columns;
+ * values are implicit: 1/deg[row]. */
+int64_t gmo_csr_from_bitmap(int64_t n, int64_t wpr, const uint32_t* bits, int32_t* rowptr, int32_t* colidx) {
+    int64_t nnz = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        rowptr[i] = (int32_t)nnz;
+        for (int64_t w = 0; w < wpr; ++w) {
+            uint32_t word = bits[i * wpr + w];
+            while (word) {
+                int b = __builtin_ctz(word);
+                word &= word - 1;
+                if (colidx) colidx[nnz] = (int32_t)(w * 32 + b);
+                ++nnz;
+            }
+        }
+    }
+    rowptr[n] = (int32_t)nnz;
+    return nnz;
+}
+int64_t gmo_upper_edges_from_bitmap(int64_t n, int64_t wpr, const uint32_t* bits, int32_t* ei, int32_t* ej) {
+    int64_t m = 0;
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = i + 1; j < n; ++j)
+            if ((bits[i * wpr + (j >> 5)] >> (j & 31)) & 1u) {
+                if (ei) { ei[m] = (int32_t)i; ej[m] = (int32_t)j; }
+                ++m;
+            }
+    return m;
+}
+void gmo_bitmap_from_upper_edges(int64_t n, int64_t wpr, int64_t m, const int32_t* ei, const int32_t* ej,
+                                 uint32_t* bits) {
+    memset(bits, 0, sizeof(uint32_t) * (size_t)(n * wpr));
+    for (int64_t e = 0; e < m; ++e) {
+        int64_t i = ei[e], j = ej[e];
+        bits[i * wpr + (j >> 5)] |= 1u << (j & 31);
+        bits[j * wpr + (i >> 5)] |= 1u << (i & 31);
+    }
+}
+
+/* ------------------------------------------------------------------ building blocks */
+/* model/gnn.py:60-61  A @ H with A = D^-1 A (diffusion.py:255-256): out[i] = sum_j (1/deg_i) * H[j],
+ * neighbours in ascending j, one fmaf per term. */
+void gmo_spmm_mean(int64_t n, const int32_t* rowptr, const int32_t* colidx, const float* H, int64_t ldh,
+                   int64_t d, float* out, int64_t ldo) {
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t i = 0; i < n; ++i) {
+        float* o = out + i * ldo;
+        for (int64_t c = 0; c < d; ++c) o[c] = 0.0f;
+        int32_t b = rowptr[i], e = rowptr[i + 1];
+        if (e == b) continue;
+        float inv = 1.0f / (float)(e - b);
+        for (int32_t p = b; p < e; ++p) {
+            const float* hrow = H + (int64_t)colidx[p] * ldh;
+            for (int64_t c = 0; c < d; ++c) o[c] = fmaf(hrow[c], inv, o[c]);
+        }
+    }
+}
+
+/* nn.Linear (+ReLU): C[m][n] = (sum_k fmaf chain, k ascending, from 0) + bias[n]. */
+void gmo_linear(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw,
+                const float* bias, float* C, int64_t ldc, int relu) {
+    float* Wt = (float*)malloc(sizeof(float) * (size_t)(K * N));
+#pragma omp parallel for schedule(static)
+    for (int64_t k = 0; k < K; ++k)
+        for (int64_t nn = 0; nn < N; ++nn) Wt[k * N + nn] = W[nn * ldw + k];
+    enum { RB = 8, NB = 256 };
+    int64_t nrb = (M + RB - 1) / RB;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t rb = 0; rb < nrb; ++rb) {
+        int64_t m0 = rb * RB;
+        int64_t mr = M - m0 < RB ? M - m0 : RB;
+        float acc[RB][NB];
+        for (int64_t n0 = 0; n0 < N; n0 += NB) {
+            int64_t nb = N - n0 < NB ? N - n0 : NB;
+            for (int64_t r = 0; r < mr; ++r)
+                for (int64_t c = 0; c < nb; ++c) acc[r][c] = 0.0f;
+            for (int64_t k = 0; k < K; ++k) {
+                const float* wrow = Wt + k * N + n0;
+                for (int64_t r = 0; r < mr; ++r) {
+                    float a = A[(m0 + r) * lda + k];
+                    float* ar = acc[r];
+                    for (int64_t c = 0; c < nb; ++c) ar[c] = fmaf(a, wrow[c], ar[c]);
+                }
+            }
+            for (int64_t r = 0; r < mr; ++r)
+                for (int64_t c = 0; c < nb; ++c) {
+                    float v = acc[r][c];
+                    if (bias) v = v + bias[n0 + c];
+                    if (relu && !(v > 0.0f)) v = 0.0f;
+                    C[(m0 + r) * ldc + n0 + c] = v;
+                }
+        }
+    }
+    free(Wt);
+}
+
+/* 64-lane strided partial sums + xor butterfly: the order a 64-wide wavefront reduction produces. */
+static float wave_sum64(const float* x, int64_t N) {
+    float part[64];
+    for (int l = 0; l < 64; ++l) {
+        float s = 0.0f;
+        for (int64_t c = l; c < N; c += 64) s = s + x[c];
+        part[l] = s;
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        float nxt[64];
+        for (int l = 0; l < 64; ++l) nxt[l] = part[l] + part[l ^ off];
+        memcpy(part, nxt, sizeof(part));
+    }
+    return part[0];
+}
+
+/* nn.LayerNorm(N), eps=1e-5, biased variance (model/gnn.py:30,36) */
+void gmo_layernorm(int64_t M, int64_t N, float* X, int64_t ldx, const float* gamma, const float* beta, float eps) {
+#pragma omp parallel for schedule(static)
+    for (int64_t m = 0; m < M; ++m) {
+        float* x = X + m * ldx;
+        float tmp[4096];
+        float* d = N <= 4096 ? tmp : (float*)malloc(sizeof(float) * (size_t)N);
+        float mean = wave_sum64(x, N) / (float)N;
+        for (int64_t c = 0; c < N; ++c) { float t = x[c] - mean; d[c] = t * t; }
+        float var = wave_sum64(d, N) / (float)N;
+        float rstd = 1.0f / sqrtf(var + eps);
+        for (int64_t c = 0; c < N; ++c) {
+            float t = (x[c] - mean) * rstd;
+            float g = t * gamma[c];
+            x[c] = g + beta[c];
+        }
+        if (d != tmp) free(d);
+    }
+}
+
+/* ------------------------------------------------------------------ towers */
+/* model/gnn.py:146-176 GNNTower.forward and :440-463 MLPTower.forward (dropout is identity in eval). */
+void gmo_tower_forward(const gmo_tower_dims* d, const float* const* P, int64_t n, float t_float,
+                       const float* X_one_hot, const int32_t* Y, const int32_t* rowptr, const int32_t* colidx,
+                       float* out, float* hcat_dbg) {
+    const int ht = d->hidden_t, hX = d->hidden_X, hY = d->hidden_Y, L = d->num_layers;
+    const int Hc = gmo_tower_hidden_cat(d);
+    const int offX = 0, offY = (L + 1) * hX, offT = (L + 1) * (hX + hY);
+    float* hcat = hcat_dbg ? hcat_dbg : (float*)malloc(sizeof(float) * (size_t)(n * Hc));
+
+    /* mlp_in_t (:116-120,153) */
+    float tin[1] = {t_float};
+    float* ht0 = (float*)malloc(sizeof(float) * (size_t)ht);
+    float* ht1 = (float*)malloc(sizeof(float) * (size_t)ht);
+    gmo_linear(1, ht, 1, tin, 1, P[0], 1, P[1], ht0, ht, 1);
+    gmo_linear(1, ht, ht, ht0, ht, P[2], ht, P[3], ht1, ht, 1);
+    for (int64_t v = 0; v < n; ++v) memcpy(hcat + v * Hc + offT, ht1, sizeof(float) * (size_t)ht);
+
+    /* mlp_in_X (:121-126,154) */
+    float* tmpX = (float*)malloc(sizeof(float) * (size_t)(n * hX));
+    gmo_linear(n, hX, d->in_X, X_one_hot, d->in_X, P[4], d->in_X, P[5], tmpX, hX, 1);
+    gmo_linear(n, hX, hX, tmpX, hX, P[6], hX, P[7], hcat + offX, Hc, 1);
+    free(tmpX);
+
+    /* emb_Y (:127,155) */
+    for (int64_t v = 0; v < n; ++v)
+        memcpy(hcat + v * Hc + offY, P[8] + (int64_t)Y[v] * hY, sizeof(float) * (size_t)hY);
+
+    const int ka = hX + hY + ht;
+    float* agg = (float*)malloc(sizeof(float) * (size_t)(n * ka));
+    for (int l = 0; l < L; ++l) {
+        const float* const* Q = P + 9 + 8 * l;
+        const float* hXl = hcat + offX + l * hX;
+        const float* hYl = hcat + offY + l * hY;
+        if (!d->is_mlp) {
+            /* GNNLayer.forward (:60-68): A@[hX|hY], A@hY (= its last hY columns), concat h_t */
+            gmo_spmm_mean(n, rowptr, colidx, hXl, Hc, hX, agg, ka);
+            gmo_spmm_mean(n, rowptr, colidx, hYl, Hc, hY, agg + hX, ka);
+        } else {
+            /* MLPLayer.forward (:387-392): no aggregation */
+            for (int64_t v = 0; v < n; ++v) {
+                memcpy(agg + v * ka, hXl + v * Hc, sizeof(float) * (size_t)hX);
+                memcpy(agg + v * ka + hX, hYl + v * Hc, sizeof(float) * (size_t)hY);
+            }
+        }
+        for (int64_t v = 0; v < n; ++v) memcpy(agg + v * ka + hX + hY, ht1, sizeof(float) * (size_t)ht);
+        float* hXn = hcat + offX + (l + 1) * hX;
+        float* hYn = hcat + offY + (l + 1) * hY;
+        gmo_linear(n, hX, ka, agg, ka, Q[0], ka, Q[1], hXn, Hc, 1);
+        gmo_layernorm(n, hX, hXn, Hc, Q[2], Q[3], 1e-5f);
+        gmo_linear(n, hY, hY, agg + hX, ka, Q[4], hY, Q[5], hYn, Hc, 1);
+        gmo_layernorm(n, hY, hYn, Hc, Q[6], Q[7], 1e-5f);
+    }
+    free(agg);
+
+    /* mlp_out (:138-142,165-176) */
+    const float* const* O = P + 9 + 8 * L;
+    float* mid = (float*)malloc(sizeof(float) * (size_t)(n * Hc));
+    gmo_linear(n, Hc, Hc, hcat, Hc, O[0], Hc, O[1], mid, Hc, 1);
+    gmo_linear(n, d->out_size, Hc, mid, Hc, O[2], Hc, O[3], out, d->out_size, 0);
+    free(mid);
+    free(ht0);
+    free(ht1);
+    if (!hcat_dbg) free(hcat);
+}
+
+/* ------------------------------------------------------------------ structure denoiser */
+/* model/gnn.py:246-248  logit = W2 relu(W1 (h_i * h_j) + b1) + b2.
+ * Orders: hidden[o] = fmaf chain over k ascending starting from b1[o];
+ *         logit[c]  = (S0 + S1) + b2[c] with S_h = fmaf chain over ascending o with ((o>>2)&1)==h
+ *         (the split a 32x32 MFMA accumulator tile gives the two half-waves). */
+void gmo_pair_logits(int64_t hE, const float* hi, const float* hj, const float* W1, const float* b1,
+                     const float* W2, const float* b2, float logit[2]) {
+    float z[1024], hid[1024];
+    for (int64_t k = 0; k < hE; ++k) z[k] = hi[k] * hj[k];
+    for (int64_t o = 0; o < hE; ++o) {
+        float acc = b1[o];
+        const float* w = W1 + o * hE;
+        for (int64_t k = 0; k < hE; ++k) acc = fmaf(z[k], w[k], acc);
+        hid[o] = acc > 0.0f ? acc : 0.0f;
+    }
+    for (int c = 0; c < 2; ++c) {
+        float s[2] = {0.0f, 0.0f};
+        for (int64_t o = 0; o < hE; ++o) {
+            int hsel = (int)((o >> 2) & 1);
+            s[hsel] = fmaf(hid[o], W2[c * hE + o], s[hsel]);
+        }
+        logit[c] = (s[0] + s[1]) + b2[c];
+    }
+}
+
+void gmo_pair_score_sample(int64_t n, int64_t hE, const float* h, const float* W1, const float* b1,
+                           const float* W2, const float* b2, const uint32_t* bits_t, int64_t wpr,
+                           const float tab[8], int64_t row_begin, int64_t row_end, const float* u_or_null,
+                           uint64_t seed, uint32_t step, uint32_t* out_upper, float* logits_dbg,
+                           float* post_dbg) {
+    /* transposed W1 so the o-loop vectorises while each o keeps its k-ascending chain */
+    float* W1t = (float*)malloc(sizeof(float) * (size_t)(hE * hE));
+    for (int64_t o = 0; o < hE; ++o)
+        for (int64_t k = 0; k < hE; ++k) W1t[k * hE + o] = W1[o * hE + k];
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t i = row_begin; i < row_end; ++i) {
+        uint32_t* orow = out_upper + i * wpr;
+        for (int64_t w = 0; w < wpr; ++w) orow[w] = 0u;
+        const float* hi = h + i * hE;
+        float z[1024], hid[1024];
+        for (int64_t j = i + 1; j < n; ++j) {
+            const float* hj = h + j * hE;
+            for (int64_t k = 0; k < hE; ++k) z[k] = hi[k] * hj[k];
+            for (int64_t o = 0; o < hE; ++o) hid[o] = b1[o];
+            for (int64_t k = 0; k < hE; ++k) {
+                float zk = z[k];
+                const float* wr = W1t + k * hE;
+                for (int64_t o = 0; o < hE; ++o) hid[o] = fmaf(zk, wr[o], hid[o]);
+            }
+            float logit[2];
+            for (int c = 0; c < 2; ++c) {
+                float s[2] = {0.0f, 0.0f};
+                for (int64_t o = 0; o < hE; ++o) {
+                    float r = hid[o] > 0.0f ? hid[o] : 0.0f;
+                    int hsel = (int)((o >> 2) & 1);
+                    s[hsel] = fmaf(r, W2[c * hE + o], s[hsel]);
+                }
+                logit[c] = (s[0] + s[1]) + b2[c];
+            }
+            float q0, q1, p0, p1;
+            gmo_softmax2(logit[0], logit[1], &q0, &q1);                      /* diffusion.py:457 */
+            int e_t = (int)((bits_t[i * wpr + (j >> 5)] >> (j & 31)) & 1u);  /* diffusion.py:460-462 */
+            gmo_posterior_apply(tab, e_t, q0, q1, &p0, &p1);                 /* diffusion.py:463-464 */
+            int64_t r = pair_rank(n, i, j);
+            float u = u_or_null ? u_or_null[r] : u_E(seed, step, i, j);
+            if (draw2(u, p0, p1)) orow[j >> 5] |= 1u << (j & 31);            /* diffusion.py:421 */
+            if (logits_dbg) { logits_dbg[2 * r] = logit[0]; logits_dbg[2 * r + 1] = logit[1]; }
+            if (post_dbg) { post_dbg[2 * r] = p0; post_dbg[2 * r + 1] = p1; }
+        }
+    }
+    free(W1t);
+}
+
+/* ------------------------------------------------------------------ attributes */
+/* model/diffusion.py:879-895: softmax over the class dim of (n,F,2) logits, per-attribute posterior,
+ * draw with index f*n+v (reshape of (F,n,2), :228-230). */
+void gmo_attr_posterior_sample(int64_t n, int64_t F, const float* logits, const uint8_t* x_t, const float* tab,
+                               const float* u_or_null, uint64_t seed, uint32_t step, uint8_t* x_s,
+                               float* post_dbg) {
+#pragma omp parallel for schedule(static)
+    for (int64_t v = 0; v < n; ++v)
+        for (int64_t f = 0; f < F; ++f) {
+            const float* l = logits + (v * F + f) * 2;
+            float q0, q1, p0, p1;
+            gmo_softmax2(l[0], l[1], &q0, &q1);
+            gmo_posterior_apply(tab + 8 * f, (int)x_t[v * F + f], q0, q1, &p0, &p1);
+            int64_t idx = f * n + v;
+            float u = u_or_null ? u_or_null[idx] : u_idx64(seed, step, GMO_STREAM_X, (uint64_t)idx);
+            x_s[v * F + f] = (uint8_t)draw2(u, p0, p1);
+            if (post_dbg) { post_dbg[(v * F + f) * 2] = p0; post_dbg[(v * F + f) * 2 + 1] = p1; }
+        }
+}
+
+void gmo_onehot_from_x(int64_t n, int64_t F, const uint8_t* x, float* oh) {
+#pragma omp parallel for schedule(static)
+    for (int64_t v = 0; v < n; ++v)
+        for (int64_t f = 0; f < F; ++f) {
+            int b = x[v * F + f] != 0;
+            oh[(v * F + f) * 2] = b ? 0.0f : 1.0f;
+            oh[(v * F + f) * 2 + 1] = b ? 1.0f : 0.0f;
+        }
+}
+
+/* ------------------------------------------------------------------ trajectories */
+static void e_tables(const float* E_marginal, const float* alphas, const float* abars, int t, float tab[8]) {
+    float Qt[4], Qbs[4], Qbt[4];
+    gmo_transition(alphas[t], E_marginal[0], E_marginal[1], Qt);       /* diffusion.py:856 */
+    gmo_transition(abars[t - 1], E_marginal[0], E_marginal[1], Qbs);   /* :857 */
+    gmo_transition(abars[t], E_marginal[0], E_marginal[1], Qbt);       /* :858 */
+    gmo_posterior_table(Qt, Qbs, Qbt, tab);
+}
+
+/* one structure step: get_E_t (diffusion.py:428-472) */
+static void e_step(int64_t n, int64_t F, const gmo_tower_dims* dE, const float* const* pE,
+                   const float* const* pPair, float t_float, const float* X_oh, const int32_t* y,
+                   const uint32_t* bits_t, int64_t wpr, const float tab[8], uint64_t seed, uint32_t step,
+                   int as_reference, int32_t* rowptr, int32_t** colidx_io, uint32_t* upper, uint32_t* bits_s) {
+    (void)F;
+    int64_t hE = dE->out_size;
+    float* h = (float*)malloc(sizeof(float) * (size_t)(n * hE));
+    int64_t nnz = gmo_csr_from_bitmap(n, wpr, bits_t, rowptr, NULL);
+    free(*colidx_io);
+    *colidx_io = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1));
+    int32_t* colidx = *colidx_io;
+    gmo_csr_from_bitmap(n, wpr, bits_t, rowptr, colidx);
+    gmo_tower_forward(dE, pE, n, t_float, X_oh, y, rowptr, colidx, h, NULL);
+    if (as_reference) {
+        /* the reference re-runs the whole encoder for every 32768-pair batch (diffusion.py:444-455) */
+        int64_t P = n * (n - 1) / 2, B = 32768;
+        for (int64_t b = B; b < P; b += B) gmo_tower_forward(dE, pE, n, t_float, X_oh, y, rowptr, colidx, h, NULL);
+    }
+    gmo_pair_score_sample(n, hE, h, pPair[0], pPair[1], pPair[2], pPair[3], bits_t, wpr, tab, 0, n, NULL,
+                          seed, step, upper, NULL, NULL);
+    gmo_symmetrize_upper(n, wpr, upper, bits_s);
+    free(h);
+}
+
+void gmo_sample_sync(int T, int64_t n, int64_t F, int C, const float* X_marginal, const float* Y_marginal,
+                     const float* E_marginal, const gmo_tower_dims* dX, const float* const* pX,
+                     const gmo_tower_dims* dE, const float* const* pE, const float* const* pPair,
+                     uint64_t seed, int as_reference, uint8_t* x, int32_t* y, uint32_t* bits, int64_t wpr) {
+    float* betas = (float*)malloc(sizeof(float) * (size_t)(T + 1) * 3);
+    float *alphas = betas + (T + 1), *abars = betas + 2 * (T + 1);
+    gmo_noise_schedule(T, betas, alphas, abars);
+    gmo_prior_Y(n, C, Y_marginal, NULL, seed, y);
+    gmo_prior_E(n, wpr, E_marginal[0], E_marginal[1], NULL, seed, bits);
+    gmo_prior_X(n, F, X_marginal, NULL, seed, x);
+
+    float* X_oh = (float*)malloc(sizeof(float) * (size_t)(n * 2 * F));
+    float* logits = (float*)malloc(sizeof(float) * (size_t)(n * 2 * F));
+    float* tabX = (float*)malloc(sizeof(float) * (size_t)(8 * F));
+    uint32_t* upper = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(n * wpr));
+    uint32_t* bits_s = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(n * wpr));
+    uint8_t* x_s = (uint8_t*)malloc((size_t)(n * F));
+    int32_t* rowptr = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n + 1));
+    int32_t* colidx = NULL;
+
+    for (int s = T - 1; s >= 0; --s) {                                  /* diffusion.py:847 */
+        int t = s + 1;
+        float t_float = (float)((double)t / (double)T);                 /* :860 torch.tensor([t / T]) */
+        float tabE[8];
+        e_tables(E_marginal, alphas, abars, t, tabE);
+        gmo_onehot_from_x(n, F, x, X_oh);
+        e_step(n, F, dE, pE, pPair, t_float, X_oh, y, bits, wpr, tabE, seed, (uint32_t)t, as_reference, rowptr,
+               &colidx, upper, bits_s);                                  /* :862-872 */
+        /* pred_X uses A_t from E_t, not E_s (:875-878); rowptr/colidx still describe E_t */
+        gmo_tower_forward(dX, pX, n, t_float, X_oh, y, rowptr, colidx, logits, NULL);
+        gmo_posterior_tables_X(F, X_marginal, alphas[t], abars[t - 1], abars[t], tabX);   /* :889-891 */
+        gmo_attr_posterior_sample(n, F, logits, x, tabX, NULL, seed, (uint32_t)t, x_s, NULL);
+        memcpy(x, x_s, (size_t)(n * F));
+        memcpy(bits, bits_s, sizeof(uint32_t) * (size_t)(n * wpr));     /* :896 */
+    }
+    free(betas); free(X_oh); free(logits); free(tabX); free(upper); free(bits_s); free(x_s);
+    free(rowptr); free(colidx);
+}
+
+void gmo_sample_async(int T_X, int T_E, int64_t n, int64_t F, int C, const float* X_marginal,
+                      const float* Y_marginal, const float* E_marginal, const gmo_tower_dims* dX,
+                      const float* const* pX, const gmo_tower_dims* dE, const float* const* pE,
+                      const float* const* pPair, uint64_t seed, int as_reference, uint8_t* x, int32_t* y,
+                      uint32_t* bits, int64_t wpr) {
+    int Tm = T_X > T_E ? T_X : T_E;
+    float* sx = (float*)malloc(sizeof(float) * (size_t)(Tm + 1) * 6);
+    float *aX = sx + (Tm + 1), *abX = sx + 2 * (Tm + 1);
+    float *bE = sx + 3 * (Tm + 1), *aE = sx + 4 * (Tm + 1), *abE = sx + 5 * (Tm + 1);
+    gmo_noise_schedule(T_X, sx, aX, abX);                               /* diffusion.py:950 */
+    gmo_noise_schedule(T_E, bE, aE, abE);                               /* :951 */
+    gmo_prior_Y(n, C, Y_marginal, NULL, seed, y);                       /* :1319-1321 */
+    gmo_prior_X(n, F, X_marginal, NULL, seed, x);                       /* :1325-1327 */
+
+    float* X_oh = (float*)malloc(sizeof(float) * (size_t)(n * 2 * F));
+    float* logits = (float*)malloc(sizeof(float) * (size_t)(n * 2 * F));
+    float* tabX = (float*)malloc(sizeof(float) * (size_t)(8 * F));
+    uint8_t* x_s = (uint8_t*)malloc((size_t)(n * F));
+    for (int s = T_X - 1; s >= 0; --s) {                                /* :1330-1358 */
+        int t = s + 1;
+        float t_float = (float)((double)t / (double)T_X);
+        gmo_onehot_from_x(n, F, x, X_oh);
+        gmo_tower_forward(dX, pX, n, t_float, X_oh, y, NULL, NULL, logits, NULL);
+        gmo_posterior_tables_X(F, X_marginal, aX[t], abX[t - 1], abX[t], tabX);
+        gmo_attr_posterior_sample(n, F, logits, x, tabX, NULL, seed, (uint32_t)t, x_s, NULL);
+        memcpy(x, x_s, (size_t)(n * F));
+    }
+    gmo_prior_E(n, wpr, E_marginal[0], E_marginal[1], NULL, seed, bits); /* :1362-1365 */
+    gmo_onehot_from_x(n, F, x, X_oh);
+    uint32_t* upper = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(n * wpr));
+    uint32_t* bits_s = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(n * wpr));
+    int32_t* rowptr = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n + 1));
+    int32_t* colidx = NULL;
+    for (int s = T_E - 1; s >= 0; --s) {                                /* :1379-1401 */
+        int t = s + 1;
+        float t_float = (float)((double)t / (double)T_E);
+        float tabE[8];
+        e_tables(E_marginal, aE, abE, t, tabE);
+        e_step(n, F, dE, pE, pPair, t_float, X_oh, y, bits, wpr, tabE, seed, (uint32_t)t, as_reference, rowptr,
+               &colidx, upper, bits_s);
+        memcpy(bits, bits_s, sizeof(uint32_t) * (size_t)(n * wpr));
+    }
+    free(sx); free(X_oh); free(logits); free(tabX); free(x_s); free(upper); free(bits_s);
+    free(rowptr); free(colidx);
+}

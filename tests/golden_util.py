@@ -1,0 +1,121 @@
+"""Deterministic synthetic checkpoints + case definitions shared by tools/gen_golden.py and the tests.
+
+Weights come from numpy's frozen legacy generator (RandomState / MT19937), so the fixtures under
+tests/golden/ need to hold only the reference's OUTPUTS, not the weights.  Key names and shapes follow the
+reference's state_dicts (train_sync.py:173-181).
+"""
+import json
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# name -> config.  hidden_E stays 128 (every reference yaml uses 128; the HIP pair kernel is built for it).
+CASES = {
+    "sync_small": dict(variant="Sync", N=67, F=11, C=3, T=3, density=0.06, seed=11,
+                       gnn_X=dict(hidden_t=8, hidden_X=32, hidden_Y=16, num_gnn_layers=2, dropout=0.0),
+                       gnn_E=dict(hidden_t=8, hidden_X=32, hidden_Y=16, hidden_E=128, num_gnn_layers=2,
+                                  dropout=0.0)),
+    "sync_mid": dict(variant="Sync", N=200, F=33, C=7, T=3, density=0.03, seed=12,
+                     gnn_X=dict(hidden_t=16, hidden_X=64, hidden_Y=32, num_gnn_layers=2, dropout=0.0),
+                     gnn_E=dict(hidden_t=16, hidden_X=64, hidden_Y=32, hidden_E=128, num_gnn_layers=2,
+                                dropout=0.0)),
+    "async_mid": dict(variant="Async", N=130, F=20, C=4, T_X=2, T_E=3, density=0.04, seed=13,
+                      mlp_X=dict(hidden_t=8, hidden_X=48, hidden_Y=16, num_mlp_layers=2, dropout=0.0),
+                      gnn_E=dict(hidden_t=8, hidden_X=32, hidden_Y=16, hidden_E=128, num_gnn_layers=2,
+                                 dropout=0.0)),
+    # full hidden sizes of configs/*/train_Sync.yaml at a small node count: towers + pair stage only
+    "tower_full": dict(variant="Sync", N=96, F=40, C=10, T=3, density=0.05, seed=14,
+                       gnn_X=dict(hidden_t=16, hidden_X=512, hidden_Y=64, num_gnn_layers=2, dropout=0.0),
+                       gnn_E=dict(hidden_t=16, hidden_X=512, hidden_Y=64, hidden_E=128, num_gnn_layers=2,
+                                  dropout=0.0)),
+}
+
+
+def marginals(cfg):
+    rs = np.random.RandomState(cfg["seed"] + 1000)
+    F, C = cfg["F"], cfg["C"]
+    p1 = rs.uniform(0.05, 0.3, size=F).astype(np.float32)
+    X_marginal = np.stack([1.0 - p1, p1], axis=1).astype(np.float32)
+    y = rs.uniform(0.5, 1.5, size=C)
+    Y_marginal = (y / y.sum()).astype(np.float32)
+    d = np.float32(cfg["density"])
+    E_marginal = np.array([np.float32(1.0) - d, d], np.float32)
+    return X_marginal, Y_marginal, E_marginal
+
+
+def _linear(rs, out_f, in_f):
+    bound = 1.0 / np.sqrt(in_f)
+    return (rs.uniform(-bound, bound, size=(out_f, in_f)).astype(np.float32),
+            rs.uniform(-bound, bound, size=(out_f,)).astype(np.float32))
+
+
+def tower_state_dict(rs, in_X, C, hidden_t, hidden_X, hidden_Y, num_layers, out_size, is_mlp, prefix=""):
+    sd = {}
+
+    def put(name, w, b):
+        sd[prefix + name + ".weight"] = w
+        sd[prefix + name + ".bias"] = b
+
+    put("mlp_in_t.0", *_linear(rs, hidden_t, 1))
+    put("mlp_in_t.2", *_linear(rs, hidden_t, hidden_t))
+    put("mlp_in_X.0", *_linear(rs, hidden_X, in_X))
+    put("mlp_in_X.2", *_linear(rs, hidden_X, hidden_X))
+    sd[prefix + "emb_Y.weight"] = rs.normal(0, 1, size=(C, hidden_Y)).astype(np.float32)
+    lay = "mlp_layers" if is_mlp else "gnn_layers"
+    for l in range(num_layers):
+        put(f"{lay}.{l}.update_X.0", *_linear(rs, hidden_X, hidden_X + hidden_Y + hidden_t))
+        sd[prefix + f"{lay}.{l}.update_X.2.weight"] = (1 + 0.1 * rs.normal(size=hidden_X)).astype(np.float32)
+        sd[prefix + f"{lay}.{l}.update_X.2.bias"] = (0.1 * rs.normal(size=hidden_X)).astype(np.float32)
+        put(f"{lay}.{l}.update_Y.0", *_linear(rs, hidden_Y, hidden_Y))
+        sd[prefix + f"{lay}.{l}.update_Y.2.weight"] = (1 + 0.1 * rs.normal(size=hidden_Y)).astype(np.float32)
+        sd[prefix + f"{lay}.{l}.update_Y.2.bias"] = (0.1 * rs.normal(size=hidden_Y)).astype(np.float32)
+    Hc = (num_layers + 1) * (hidden_X + hidden_Y) + hidden_t
+    put("mlp_out.0", *_linear(rs, Hc, Hc))
+    put("mlp_out.2", *_linear(rs, out_size, Hc))
+    return sd
+
+
+def make_checkpoint(cfg, edge_bias=2.0, attr_bias=1.0):
+    """Returns (pred_X_state_dict, pred_E_state_dict) as name -> float32 ndarray, reference key names.
+
+    Output biases are shifted so the generated graphs stay sparse-ish along the trajectory (a trained
+    model's regime) instead of the p=0.5 coin flips an untrained head gives."""
+    rs = np.random.RandomState(cfg["seed"])
+    F, C = cfg["F"], cfg["C"]
+    if cfg["variant"] == "Sync":
+        g = cfg["gnn_X"]
+        sdX = tower_state_dict(rs, 2 * F, C, g["hidden_t"], g["hidden_X"], g["hidden_Y"],
+                               g["num_gnn_layers"], 2 * F, is_mlp=False)
+    else:
+        g = cfg["mlp_X"]
+        sdX = tower_state_dict(rs, 2 * F, C, g["hidden_t"], g["hidden_X"], g["hidden_Y"],
+                               g["num_mlp_layers"], 2 * F, is_mlp=True)
+    b = sdX["mlp_out.2.bias"]
+    b[0::2] += attr_bias
+    b[1::2] -= attr_bias
+    e = cfg["gnn_E"]
+    sdE = tower_state_dict(rs, 2 * F, C, e["hidden_t"], e["hidden_X"], e["hidden_Y"], e["num_gnn_layers"],
+                           e["hidden_E"], is_mlp=False, prefix="gnn_encoder.")
+    hE = e["hidden_E"]
+    w, bb = _linear(rs, hE, hE)
+    sdE["mlp_out.0.weight"], sdE["mlp_out.0.bias"] = w, bb
+    w, bb = _linear(rs, 2, hE)
+    bb[0] += edge_bias
+    bb[1] -= edge_bias
+    sdE["mlp_out.2.weight"], sdE["mlp_out.2.bias"] = w, bb
+    return sdX, sdE
+
+
+def golden_path(name):
+    return os.path.join(GOLDEN_DIR, name + ".npz")
+
+
+def load_golden(name):
+    z = np.load(golden_path(name), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def case_json(name):
+    return json.dumps(CASES[name], sort_keys=True)

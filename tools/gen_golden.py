@@ -1,0 +1,287 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (this container only; /root/reference never travels).
+
+What runs: the reference's own model/gnn.py and model/diffusion.py, loaded from /root/reference by file
+path.  Two seams are filled in here, both recorded in DESIGN.md:
+  * `dgl.sparse` is not installed (dgl==1.1.0+cu116, README.md:25-27).  model/diffusion.py uses five of its
+    behaviours in get_adj (:254-256) and model/gnn.py one (`A @ H`, :60-61); a torch-only module with exactly
+    those behaviours is registered as sys.modules["dgl.sparse"].  -> "parity unpinned
+    at the DGL boundary".
+  * torch.Tensor.multinomial is swapped for an inverse-CDF rule on supplied uniforms (SURVEY.md 8c
+    "Shared-RNG shim"): 2 classes: x = (u*(p0+p1) < p1); C classes: first c with u*sum < cumsum_c.
+    The uniforms come from the oracle's Philox streams (oracle/gm_oracle.h) so every draw is indexed the
+    way the build indexes it.
+Weights are synthetic (tests/golden_util.py); pre-trained checkpoints and datasets are remote fetches and
+unavailable offline.
+
+Usage:  python tools/gen_golden.py [case ...]
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import golden_util as gu  # noqa: E402
+import oracle_lib as orc  # noqa: E402
+
+REF = "/root/reference"
+
+
+# ----------------------------------------------------------------------------- dgl.sparse stand-in
+def _install_dgl_sparse_standin():
+    mod = types.ModuleType("dgl.sparse")
+
+    class SparseMatrix:
+        def __init__(self, row, col, val, shape):
+            self.row, self.col, self.val, self.shape = row, col, val, shape
+
+        def sum(self, dim):
+            assert dim == 1
+            out = torch.zeros(self.shape[0], dtype=self.val.dtype)
+            out.index_add_(0, self.row, self.val)
+            return out
+
+        def __matmul__(self, dense):
+            out = torch.zeros(self.shape[0], dense.shape[1], dtype=dense.dtype)
+            out.index_add_(0, self.row, dense[self.col] * self.val[:, None])
+            return out
+
+    class DiagMatrix:
+        def __init__(self, val):
+            self.val = val
+
+        def __pow__(self, p):
+            return DiagMatrix(self.val ** p)
+
+        def __matmul__(self, sp):
+            return SparseMatrix(sp.row, sp.col, sp.val * self.val[sp.row], sp.shape)
+
+    def spmatrix(indices, shape):
+        return SparseMatrix(indices[0], indices[1], torch.ones(indices.shape[1]), tuple(shape))
+
+    def diag(v):
+        return DiagMatrix(v)
+
+    mod.SparseMatrix, mod.DiagMatrix, mod.spmatrix, mod.diag = SparseMatrix, DiagMatrix, spmatrix, diag
+    dgl = types.ModuleType("dgl")
+    dgl.sparse = mod
+    sys.modules.setdefault("dgl", dgl)
+    sys.modules["dgl.sparse"] = mod
+
+
+def load_reference():
+    _install_dgl_sparse_standin()
+    pkg = types.ModuleType("gmref")
+    pkg.__path__ = [os.path.join(REF, "model")]
+    sys.modules["gmref"] = pkg
+    mods = {}
+    for name in ("gnn", "diffusion"):
+        spec = importlib.util.spec_from_file_location(f"gmref.{name}", os.path.join(REF, "model", f"{name}.py"))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[f"gmref.{name}"] = m
+        spec.loader.exec_module(m)
+        mods[name] = m
+    return mods["gnn"], mods["diffusion"]
+
+
+# ----------------------------------------------------------------------------- shared-RNG shim
+class Ctx:
+    site = "Y"
+    e_step = 0
+    x_step = 0
+    seed = 0
+    N = 0
+    F = 0
+
+
+def _shim_multinomial(self, num_samples, replacement=False, *, generator=None):
+    assert num_samples == 1
+    p = self.detach().float()
+    R, Cc = p.shape
+    if Ctx.site == "Y":
+        u = orc.uniform_Y(Ctx.seed, R)
+    elif Ctx.site == "E_prior":
+        assert R == Ctx.N * Ctx.N
+        u = orc.uniform_E_prior(Ctx.seed, Ctx.N)
+    elif Ctx.site == "X":
+        assert R == Ctx.N * Ctx.F
+        u = orc.uniform_X(Ctx.seed, Ctx.x_step, Ctx.N, Ctx.F)
+    elif Ctx.site == "E":
+        assert R == Ctx.N * (Ctx.N - 1) // 2
+        u = orc.uniform_E(Ctx.seed, Ctx.e_step, Ctx.N)
+    else:
+        raise RuntimeError(Ctx.site)
+    u = torch.from_numpy(u)
+    if Cc == 2:
+        s = p[:, 0] + p[:, 1]
+        x = (u * s < p[:, 1]).long()
+    else:
+        s = torch.zeros(R)
+        for c in range(Cc):
+            s = s + p[:, c]
+        us = u * s
+        cum = torch.zeros(R)
+        x = torch.full((R,), Cc - 1, dtype=torch.long)
+        done = torch.zeros(R, dtype=torch.bool)
+        for c in range(Cc):
+            cum = cum + p[:, c]
+            hit = (us < cum) & ~done
+            x[hit] = c
+            done |= hit
+    return x.unsqueeze(1)
+
+
+def to_t(sd):
+    return {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
+
+
+def run_case(name, gnn, diffusion):
+    cfg = gu.CASES[name]
+    N, F = cfg["N"], cfg["F"]
+    Xm, Ym, Em = gu.marginals(cfg)
+    sdX, sdE = gu.make_checkpoint(cfg)
+    if cfg["variant"] == "Sync":
+        model = diffusion.ModelSync(T=cfg["T"], X_marginal=torch.from_numpy(Xm), Y_marginal=torch.from_numpy(Ym),
+                                    E_marginal=torch.from_numpy(Em), gnn_X_config=cfg["gnn_X"],
+                                    gnn_E_config=cfg["gnn_E"], num_nodes=N)
+    else:
+        model = diffusion.ModelAsync(T_X=cfg["T_X"], T_E=cfg["T_E"], X_marginal=torch.from_numpy(Xm),
+                                     Y_marginal=torch.from_numpy(Ym), E_marginal=torch.from_numpy(Em),
+                                     mlp_X_config=cfg["mlp_X"], gnn_E_config=cfg["gnn_E"], num_nodes=N)
+    model.graph_encoder.pred_X.load_state_dict(to_t(sdX))      # strict: proves key/shape compatibility
+    model.graph_encoder.pred_E.load_state_dict(to_t(sdE))
+    model.eval()
+
+    out = {}
+    Ctx.seed, Ctx.N, Ctx.F = cfg["seed"], N, F
+    Ctx.site, Ctx.e_step, Ctx.x_step = "Y", 0, 0
+    T_E = cfg["T"] if cfg["variant"] == "Sync" else cfg["T_E"]
+    T_X = cfg["T"] if cfg["variant"] == "Sync" else cfg["T_X"]
+    cap = {"logits": [], "h": None}
+
+    # schedule tables
+    if cfg["variant"] == "Sync":
+        out["alphas"] = model.noise_schedule.alphas.numpy()
+        out["alpha_bars"] = model.noise_schedule.alpha_bars.numpy()
+    else:
+        out["alphas_X"] = model.noise_schedule_X.alphas.numpy()
+        out["alpha_bars_X"] = model.noise_schedule_X.alpha_bars.numpy()
+        out["alphas_E"] = model.noise_schedule_E.alphas.numpy()
+        out["alpha_bars_E"] = model.noise_schedule_E.alpha_bars.numpy()
+
+    orig_sample_E, orig_sample_X = model.sample_E, model.sample_X
+    orig_sample_E_infer, orig_get_E_t = model.sample_E_infer, model.get_E_t
+    orig_posterior = model.posterior
+
+    def sample_E(prob):
+        Ctx.site = "E_prior"
+        r = orig_sample_E(prob)
+        Ctx.site = "Y"
+        out["E_T_nz"] = r.nonzero().numpy().astype(np.int32)
+        return r
+
+    def sample_X(prob):
+        Ctx.site = "X"
+        r = orig_sample_X(prob)
+        Ctx.site = "Y"
+        tag = f"x{Ctx.x_step}"
+        out[f"{tag}_X_prob"] = prob.detach().contiguous().numpy().astype(np.float32)     # (F,N,2)
+        out[f"{tag}_X_out"] = r.reshape(N, F, 2)[:, :, 1].numpy().astype(np.uint8)       # (N,F)
+        return r
+
+    def sample_E_infer(prob):
+        Ctx.site = "E"
+        r = orig_sample_E_infer(prob)
+        Ctx.site = "Y"
+        out[f"e{Ctx.e_step}_E_prob"] = prob.numpy().astype(np.float32)
+        return r
+
+    def get_E_t(device, loader, pred_E_func, t_float, X_t_one_hot, Y_0, E_t, Q_t_E, Q_bar_s_E, Q_bar_t_E, bs):
+        t = int(round(float(t_float.item()) * T_E))
+        Ctx.e_step = t
+        if cfg["variant"] == "Sync":
+            Ctx.x_step = t
+        cap["logits"], cap["h"] = [], None
+        tag = f"e{t}"
+        out[f"{tag}_E_in_nz"] = E_t.nonzero().numpy().astype(np.int32)
+        out[f"{tag}_X_in"] = X_t_one_hot.reshape(N, F, 2)[:, :, 1].numpy().astype(np.uint8)
+        out[f"{tag}_Q"] = torch.stack([Q_t_E, Q_bar_s_E, Q_bar_t_E]).numpy().astype(np.float32)
+        A_t, E_s = orig_get_E_t(device, loader, pred_E_func, t_float, X_t_one_hot, Y_0, E_t, Q_t_E, Q_bar_s_E,
+                                Q_bar_t_E, bs)
+        out[f"{tag}_A_row"] = A_t.row.numpy().astype(np.int32)
+        out[f"{tag}_A_col"] = A_t.col.numpy().astype(np.int32)
+        out[f"{tag}_A_val"] = A_t.val.numpy().astype(np.float32)
+        out[f"{tag}_h"] = cap["h"]
+        out[f"{tag}_pair_logits"] = np.concatenate(cap["logits"], 0).astype(np.float32)
+        out[f"{tag}_E_out_nz"] = E_s.nonzero().numpy().astype(np.int32)
+        return A_t, E_s
+
+    model.sample_E, model.sample_X = sample_E, sample_X
+    model.sample_E_infer, model.get_E_t = sample_E_infer, get_E_t
+
+    def hook_pred_E(mod, args, res):
+        cap["logits"].append(res.detach().numpy().copy())
+
+    def hook_enc(mod, args, res):
+        if cap["h"] is None:
+            cap["h"] = res.detach().numpy().astype(np.float32).copy()
+
+    def pre_pred_X(mod, args):
+        if cfg["variant"] == "Async":
+            Ctx.x_step = int(round(float(args[0].item()) * T_X))
+
+    def hook_pred_X(mod, args, res):
+        out[f"x{Ctx.x_step}_X_logits"] = res.detach().numpy().astype(np.float32).copy()   # (N,F,2)
+        if cfg["variant"] == "Async":
+            out[f"x{Ctx.x_step}_X_in"] = args[1].reshape(N, F, 2)[:, :, 1].numpy().astype(np.uint8)
+
+    model.graph_encoder.pred_E.register_forward_hook(hook_pred_E)
+    model.graph_encoder.pred_E.gnn_encoder.register_forward_hook(hook_enc)
+    model.graph_encoder.pred_X.register_forward_pre_hook(pre_pred_X)
+    model.graph_encoder.pred_X.register_forward_hook(hook_pred_X)
+
+    saved = torch.Tensor.multinomial
+    torch.Tensor.multinomial = _shim_multinomial
+    try:
+        X, Y1h, E = model.sample(batch_size=1000, num_workers=0)
+    finally:
+        torch.Tensor.multinomial = saved
+
+    out["final_X"] = X[:, :, 1].T.contiguous().numpy().astype(np.uint8)      # (N,F) from (F,N,2)
+    out["final_Y"] = Y1h.argmax(1).numpy().astype(np.int32)
+    out["final_E_nz"] = E.nonzero().numpy().astype(np.int32)
+    out["Y"] = out["final_Y"]
+    out["config_json"] = np.frombuffer(gu.case_json(name).encode(), dtype=np.uint8)
+
+    # a few direct calls of BaseModel.posterior on random priors (pins the closed-form tables)
+    g = torch.Generator().manual_seed(5)
+    prior = torch.rand(64, 2, generator=g)
+    prior = prior / prior.sum(1, keepdim=True)
+    z = torch.randint(0, 2, (64,), generator=g)
+    Q = torch.from_numpy(out[f"e{T_E}_Q"])
+    out["post_prior"] = prior.numpy()
+    out["post_z"] = z.numpy().astype(np.int32)
+    out["post_out"] = orig_posterior(torch.nn.functional.one_hot(z, 2).float(), Q[0], Q[1], Q[2], prior).numpy()
+
+    os.makedirs(gu.GOLDEN_DIR, exist_ok=True)
+    np.savez_compressed(gu.golden_path(name), **out)
+    nE = len(out["final_E_nz"])
+    print(f"{name}: wrote {gu.golden_path(name)}  ({os.path.getsize(gu.golden_path(name)) / 1e3:.0f} kB)  "
+          f"final nnz={nE} X ones={int(out['final_X'].sum())}")
+
+
+def main():
+    torch.set_grad_enabled(False)
+    gnn, diffusion = load_reference()
+    names = sys.argv[1:] or list(gu.CASES)
+    for name in names:
+        run_case(name, gnn, diffusion)
+
+
+if __name__ == "__main__":
+    main()
