@@ -1,0 +1,235 @@
+// gm_adjacency.hip -- adjacency state as a symmetric bitmap + CSR construction.
+// Replaces the dense (N,N) int64 E_t of model/diffusion.py:422-424 and get_adj (model/diffusion.py:239-256):
+// `E_t.nonzero()` enumerates row-major, so a CSR with ascending columns is the same edge order; the values of
+// D^-1 A are 1/deg[row] and stay implicit.  All kernels are HBM-bound bit/integer work.
+#include "gm_common.h"
+
+namespace gm {
+
+// ---------------------------------------------------------------- dense <-> bitmap
+// one wave per 64 consecutive columns of one row; __ballot packs 64 compare results into two words.
+__global__ void k_bitmap_from_dense(int64_t n, int64_t wpr, const int64_t* __restrict__ dense,
+                                    uint32_t* __restrict__ bits) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t chunks = wpr >> 1;  // 64-column chunks per row (wpr is even)
+    if (wave >= n * chunks) return;
+    const int64_t i = wave / chunks, c = wave % chunks;
+    const int64_t j = c * 64 + lane;
+    bool nz = (j < n) && (dense[i * n + j] != 0);
+    unsigned long long m = __ballot(nz);
+    if (lane == 0) {
+        bits[i * wpr + 2 * c] = (uint32_t)m;
+        bits[i * wpr + 2 * c + 1] = (uint32_t)(m >> 32);
+    }
+}
+
+__global__ void k_dense_from_bitmap(int64_t n, int64_t wpr, const uint32_t* __restrict__ bits,
+                                    int64_t* __restrict__ dense) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * n) return;
+    const int64_t i = idx / n, j = idx % n;
+    dense[idx] = (bits[i * wpr + (j >> 5)] >> (j & 31)) & 1u;
+}
+
+// ---------------------------------------------------------------- symmetrize
+// One wave handles 32 rows (lane & 31 = row within the tile; both half-waves do the same rows, different words).
+// For the word (i, w): own bits (j >= i) come from upper[i][w]; bits j < i come from column-word (i>>5) of rows
+// 32w .. 32w+31 -- 32 wave-uniform-per-half loads, i.e. a 32x32 bit-tile transpose.
+__global__ void k_symmetrize(int64_t n, int64_t wpr, const uint32_t* __restrict__ upper, uint32_t* __restrict__ sym) {
+    const int lane = threadIdx.x & 63;
+    const int li = lane & 31;
+    const int half = lane >> 5;
+    const int64_t I = blockIdx.x;  // row tile
+    const int64_t i = I * 32 + li;
+    const int wavesPerBlock = blockDim.x >> 6;
+    const int wv = threadIdx.x >> 6;
+    for (int64_t w = (int64_t)(wv * 2 + half); w < wpr; w += 2 * wavesPerBlock) {
+        uint32_t res = 0;
+        if (i < n && w * 32 < n) {
+            if (w >= I) {
+                uint32_t own = upper[i * wpr + w];
+                if (w == I) own &= ~((1u << li) - 1u);  // keep j >= i
+                res = own;
+            }
+            if (w <= I) {
+                for (int b = 0; b < 32; ++b) {
+                    const int64_t jr = w * 32 + b;
+                    if (jr < i && jr < n) {
+                        uint32_t word = upper[jr * wpr + I];
+                        res |= ((word >> li) & 1u) << b;
+                    }
+                }
+            }
+            const int64_t rem = n - w * 32;  // clear padding bits
+            if (rem < 32) res &= (1u << rem) - 1u;
+        }
+        if (i < n) sym[i * wpr + w] = res;
+    }
+}
+
+// ---------------------------------------------------------------- CSR
+__device__ __forceinline__ uint32_t masked_word(const uint32_t* bits, int64_t wpr, int64_t i, int64_t w, int upper_only) {
+    uint32_t word = bits[i * wpr + w];
+    if (upper_only) {
+        const int64_t I = i >> 5;
+        if (w < I) word = 0;
+        else if (w == I) {
+            const int li = (int)(i & 31);
+            word = (li == 31) ? 0u : (word & ~((2u << li) - 1u));  // keep j > i
+        }
+    }
+    return word;
+}
+
+// degree per row: one wave per row
+__global__ void k_row_degree(int64_t n, int64_t wpr, const uint32_t* __restrict__ bits, int upper_only,
+                             int32_t* __restrict__ deg) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= n) return;
+    int cnt = 0;
+    for (int64_t w = lane; w < wpr; w += 64) cnt += __popc(masked_word(bits, wpr, i, w, upper_only));
+    for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if (lane == 0) deg[i] = cnt;
+}
+
+// exclusive scan of deg[0..n) into rowptr[0..n] (in place: deg == rowptr allowed), single block of 1024 threads
+__global__ void k_exclusive_scan(int64_t n, int32_t* __restrict__ rowptr) {
+    __shared__ int32_t wsum[16];
+    __shared__ int32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += 1024) {
+        const int64_t idx = base + tid;
+        int32_t v = idx < n ? rowptr[idx] : 0;
+        int32_t inc = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            int32_t t = __shfl_up(inc, off);
+            if (lane >= off) inc += t;
+        }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        int32_t woff = 0;
+        for (int k = 0; k < wv; ++k) woff += wsum[k];
+        const int32_t carry = carry_s;
+        if (idx < n) rowptr[idx] = carry + woff + inc - v;
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+    if (tid == 0) rowptr[n] = carry_s;
+}
+
+// column indices in ascending order: one wave per row, lanes take words, in-wave prefix of popcounts
+__global__ void k_csr_fill(int64_t n, int64_t wpr, const uint32_t* __restrict__ bits, int upper_only,
+                           const int32_t* __restrict__ rowptr, int64_t capacity, int32_t* __restrict__ colidx,
+                           int32_t* __restrict__ rows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= n) return;
+    int64_t base = rowptr[i];
+    for (int64_t w0 = 0; w0 < wpr; w0 += 64) {
+        const int64_t w = w0 + lane;
+        uint32_t word = w < wpr ? masked_word(bits, wpr, i, w, upper_only) : 0u;
+        int cnt = __popc(word);
+        int inc = cnt;
+        for (int off = 1; off < 64; off <<= 1) {
+            int t = __shfl_up(inc, off);
+            if (lane >= off) inc += t;
+        }
+        int64_t pos = base + inc - cnt;
+        while (word) {
+            const int b = __ffs(word) - 1;
+            word &= word - 1;
+            if (pos < capacity) {
+                colidx[pos] = (int32_t)(w * 32 + b);
+                if (rows) rows[pos] = (int32_t)i;
+            }
+            ++pos;
+        }
+        base += __shfl(inc, 63);
+    }
+}
+
+__global__ void k_bitmap_from_edges(int64_t n, int64_t wpr, int64_t m, const int32_t* __restrict__ ei,
+                                    const int32_t* __restrict__ ej, uint32_t* __restrict__ bits) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m) return;
+    const int64_t i = ei[e], j = ej[e];
+    if (i < 0 || j < 0 || i >= n || j >= n) return;
+    atomicOr(&bits[i * wpr + (j >> 5)], 1u << (j & 31));
+    atomicOr(&bits[j * wpr + (i >> 5)], 1u << (i & 31));
+}
+
+}  // namespace gm
+
+using namespace gm;
+
+static int check_bitmap_args(int64_t n, int64_t wpr) {
+    GM_REQUIRE(n > 0 && n < (1ll << 31), "n=%lld out of range", (long long)n);
+    GM_REQUIRE(wpr >= (n + 31) / 32 && (wpr % 4) == 0, "wpr=%lld must be a multiple of 4 and >= ceil(n/32)", (long long)wpr);
+    return GM_OK;
+}
+
+extern "C" int gm_bitmap_from_dense_i64(int64_t n, int64_t wpr, const int64_t* dense, uint32_t* bits, gm_stream_t stream) {
+    if (int rc = check_bitmap_args(n, wpr)) return rc;
+    GM_REQUIRE(dense && bits, "null pointer");
+    const int64_t waves = n * (wpr / 2);
+    const int64_t blocks = (waves + 3) / 4;
+    hipLaunchKernelGGL(k_bitmap_from_dense, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), n, wpr, dense, bits);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+extern "C" int gm_dense_i64_from_bitmap(int64_t n, int64_t wpr, const uint32_t* bits, int64_t* dense, gm_stream_t stream) {
+    if (int rc = check_bitmap_args(n, wpr)) return rc;
+    GM_REQUIRE(dense && bits, "null pointer");
+    const int64_t blocks = (n * n + 255) / 256;
+    GM_REQUIRE(blocks < (1ll << 31), "n too large for a dense materialisation");
+    hipLaunchKernelGGL(k_dense_from_bitmap, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), n, wpr, bits, dense);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+extern "C" int gm_symmetrize_upper(int64_t n, int64_t wpr, const uint32_t* upper, uint32_t* sym, gm_stream_t stream) {
+    if (int rc = check_bitmap_args(n, wpr)) return rc;
+    GM_REQUIRE(upper && sym && upper != sym, "null or aliased pointer");
+    const int64_t tiles = (n + 31) / 32;
+    hipLaunchKernelGGL(k_symmetrize, dim3((unsigned)tiles), dim3(256), 0, as_stream(stream), n, wpr, upper, sym);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+extern "C" int gm_csr_rowptr(int64_t n, int64_t wpr, const uint32_t* bits, int upper_only, int32_t* rowptr, gm_stream_t stream) {
+    if (int rc = check_bitmap_args(n, wpr)) return rc;
+    GM_REQUIRE(bits && rowptr, "null pointer");
+    hipLaunchKernelGGL(k_row_degree, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, as_stream(stream), n, wpr, bits, upper_only, rowptr);
+    GM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, as_stream(stream), n, rowptr);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+extern "C" int gm_csr_fill(int64_t n, int64_t wpr, const uint32_t* bits, int upper_only, const int32_t* rowptr,
+                           int64_t capacity, int32_t* colidx, int32_t* rows, gm_stream_t stream) {
+    if (int rc = check_bitmap_args(n, wpr)) return rc;
+    GM_REQUIRE(bits && rowptr && (colidx || capacity == 0), "null pointer");
+    if (capacity == 0) return GM_OK;
+    hipLaunchKernelGGL(k_csr_fill, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, as_stream(stream), n, wpr, bits, upper_only,
+                       rowptr, capacity, colidx, rows);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+extern "C" int gm_bitmap_from_upper_edges(int64_t n, int64_t wpr, int64_t m, const int32_t* ei, const int32_t* ej,
+                                          uint32_t* bits, gm_stream_t stream) {
+    if (int rc = check_bitmap_args(n, wpr)) return rc;
+    GM_REQUIRE(bits && m >= 0 && (m == 0 || (ei && ej)), "bad edge list");
+    GM_HIP(hipMemsetAsync(bits, 0, sizeof(uint32_t) * (size_t)(n * wpr), as_stream(stream)));
+    if (m == 0) return GM_OK;
+    hipLaunchKernelGGL(k_bitmap_from_edges, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, as_stream(stream), n, wpr, m, ei, ej, bits);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}

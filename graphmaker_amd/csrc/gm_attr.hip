@@ -1,0 +1,148 @@
+// gm_attr.hip -- attribute posterior + draw, one-hot conversions and the three priors.  HBM-bound elementwise work.
+//   gm_attr_posterior_sample : softmax over the class dim (model/diffusion.py:879), per-attribute posterior
+//                              (:884-894 via BaseModel.posterior :351-406) and sample_X (:214-237) in one pass,
+//                              writing the uint8 state and (optionally) the (n,2F) float one-hot the towers read.
+//   gm_prior_Y / gm_prior_X / gm_prior_E : model/diffusion.py:831-844 (sample_E :188-212 keeps diagonal draws).
+#include "gm_common.h"
+
+namespace gm {
+
+__global__ void k_attr_posterior_sample(int64_t n, int64_t F, const float* __restrict__ logits,
+                                        const uint8_t* __restrict__ x_t, const float* __restrict__ tab,
+                                        const float* __restrict__ u, uint64_t seed, uint32_t step,
+                                        uint8_t* __restrict__ x_s, float* __restrict__ onehot, float* __restrict__ post) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n * F) return;
+    const int64_t v = g / F, f = g % F;
+    const float2 l = *reinterpret_cast<const float2*>(logits + 2 * g);
+    float q0, q1, p0, p1;
+    softmax2(l.x, l.y, q0, q1);
+    posterior2(tab + 8 * f, (int)x_t[g], q0, q1, p0, p1);
+    const int64_t idx = f * n + v;   // reshape(-1, 2) of the (F, n, 2) tensor, model/diffusion.py:228-230
+    const float uu = u ? u[idx] : u_idx64(seed, step, STREAM_X, (uint64_t)idx);
+    const bool b = draw2(uu, p0, p1);
+    x_s[g] = b ? 1 : 0;
+    if (onehot) *reinterpret_cast<float2*>(onehot + 2 * g) = b ? make_float2(0.f, 1.f) : make_float2(1.f, 0.f);
+    if (post) *reinterpret_cast<float2*>(post + 2 * g) = make_float2(p0, p1);
+}
+
+__global__ void k_onehot_from_x(int64_t total, const uint8_t* __restrict__ x, float* __restrict__ onehot) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    *reinterpret_cast<float2*>(onehot + 2 * g) = x[g] ? make_float2(0.f, 1.f) : make_float2(1.f, 0.f);
+}
+__global__ void k_x_from_onehot(int64_t total, const float* __restrict__ onehot, uint8_t* __restrict__ x) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const float2 o = *reinterpret_cast<const float2*>(onehot + 2 * g);
+    x[g] = o.y > o.x ? 1 : 0;
+}
+
+__global__ void k_prior_Y(int64_t n, int C, const float* __restrict__ Ym, const float* __restrict__ u, uint64_t seed,
+                          int32_t* __restrict__ y) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    float sum = 0.0f;
+    for (int c = 0; c < C; ++c) sum = sum + Ym[c];
+    const float uu = u ? u[v] : u_label(seed, (uint32_t)v);
+    const float us = uu * sum;
+    float cum = 0.0f;
+    int pick = C - 1;
+    for (int c = 0; c < C; ++c) {
+        cum = cum + Ym[c];
+        if (us < cum) { pick = c; break; }
+    }
+    y[v] = pick;
+}
+
+__global__ void k_prior_X(int64_t n, int64_t F, const float* __restrict__ Xm, const float* __restrict__ u, uint64_t seed,
+                          uint8_t* __restrict__ x, float* __restrict__ onehot) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n * F) return;
+    const int64_t v = g / F, f = g % F;
+    const int64_t idx = f * n + v;
+    const float uu = u ? u[idx] : u_idx64(seed, 0u, STREAM_X, (uint64_t)idx);
+    const bool b = draw2(uu, Xm[2 * f], Xm[2 * f + 1]);
+    x[g] = b ? 1 : 0;
+    if (onehot) *reinterpret_cast<float2*>(onehot + 2 * g) = b ? make_float2(0.f, 1.f) : make_float2(1.f, 0.f);
+}
+
+// upper[i][w] bits j >= i (diagonal included), one thread per word
+__global__ void k_prior_E_upper(int64_t n, int64_t wpr, float p0, float p1, const float* __restrict__ u, uint64_t seed,
+                                uint32_t* __restrict__ upper) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n * wpr) return;
+    const int64_t i = g / wpr, w = g % wpr;
+    uint32_t word = 0;
+    if (w >= (i >> 5)) {
+        for (int b = 0; b < 32; ++b) {
+            const int64_t j = w * 32 + b;
+            if (j >= i && j < n) {
+                const int64_t idx = i * n + j;
+                const float uu = u ? u[idx] : u_idx64(seed, 0u, STREAM_E_PRIOR, (uint64_t)idx);
+                if (draw2(uu, p0, p1)) word |= 1u << b;
+            }
+        }
+    }
+    upper[g] = word;
+}
+
+}  // namespace gm
+
+using namespace gm;
+
+static inline unsigned blocks_for(int64_t total) { return (unsigned)((total + 255) / 256); }
+
+extern "C" int gm_attr_posterior_sample(int64_t n, int64_t F, const float* logits, const uint8_t* x_t, const float* tab,
+                                        const float* u, uint64_t seed, uint32_t step, uint8_t* x_s, float* onehot_out,
+                                        float* post_dbg, gm_stream_t stream) {
+    GM_REQUIRE(n > 0 && F > 0 && logits && x_t && tab && x_s, "bad arguments");
+    GM_REQUIRE(n * F < (1ll << 39), "n*F too large");
+    GM_REQUIRE(aligned(logits, 8) && (!onehot_out || aligned(onehot_out, 8)) && (!post_dbg || aligned(post_dbg, 8)),
+               "logits/onehot/post must be 8-byte aligned");
+    hipLaunchKernelGGL(k_attr_posterior_sample, dim3(blocks_for(n * F)), dim3(256), 0, as_stream(stream), n, F, logits, x_t, tab,
+                       u, seed, step, x_s, onehot_out, post_dbg);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+extern "C" int gm_onehot_from_x(int64_t n, int64_t F, const uint8_t* x, float* onehot, gm_stream_t stream) {
+    GM_REQUIRE(n > 0 && F > 0 && x && onehot && aligned(onehot, 8), "bad arguments");
+    hipLaunchKernelGGL(k_onehot_from_x, dim3(blocks_for(n * F)), dim3(256), 0, as_stream(stream), n * F, x, onehot);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+extern "C" int gm_x_from_onehot(int64_t n, int64_t F, const float* onehot, uint8_t* x, gm_stream_t stream) {
+    GM_REQUIRE(n > 0 && F > 0 && x && onehot && aligned(onehot, 8), "bad arguments");
+    hipLaunchKernelGGL(k_x_from_onehot, dim3(blocks_for(n * F)), dim3(256), 0, as_stream(stream), n * F, onehot, x);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+extern "C" int gm_prior_Y(int64_t n, int C, const float* Y_marginal, const float* u, uint64_t seed, int32_t* y,
+                          gm_stream_t stream) {
+    GM_REQUIRE(n > 0 && C > 0 && Y_marginal && y, "bad arguments");
+    hipLaunchKernelGGL(k_prior_Y, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), n, C, Y_marginal, u, seed, y);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+extern "C" int gm_prior_X(int64_t n, int64_t F, const float* X_marginal, const float* u, uint64_t seed, uint8_t* x,
+                          float* onehot_out, gm_stream_t stream) {
+    GM_REQUIRE(n > 0 && F > 0 && X_marginal && x, "bad arguments");
+    GM_REQUIRE(!onehot_out || aligned(onehot_out, 8), "onehot must be 8-byte aligned");
+    hipLaunchKernelGGL(k_prior_X, dim3(blocks_for(n * F)), dim3(256), 0, as_stream(stream), n, F, X_marginal, u, seed, x,
+                       onehot_out);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+extern "C" int gm_prior_E(int64_t n, int64_t wpr, float p0, float p1, const float* u, uint64_t seed, uint32_t* upper_ws,
+                          uint32_t* bits, gm_stream_t stream) {
+    GM_REQUIRE(n > 0 && wpr >= (n + 31) / 32 && wpr % 4 == 0 && upper_ws && bits && upper_ws != bits, "bad arguments");
+    hipLaunchKernelGGL(k_prior_E_upper, dim3(blocks_for(n * wpr)), dim3(256), 0, as_stream(stream), n, wpr, p0, p1, u, seed,
+                       upper_ws);
+    GM_LAUNCH_CHECK();
+    return gm_symmetrize_upper(n, wpr, upper_ws, bits, stream);
+}

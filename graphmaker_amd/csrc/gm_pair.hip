@@ -1,0 +1,257 @@
+// gm_pair.hip -- the all-pairs structure denoiser: the hot loop of get_E_t (model/diffusion.py:444-470).
+//
+// For every unordered pair i<j of the rows this call owns:
+//     z      = h_i * h_j                                   (model/gnn.py:246)
+//     hid    = relu(W1 z + b1)      128x128                (model/gnn.py:227-231,248)
+//     logit  = W2 hid + b2          2x128
+//     q      = softmax(logit)                              (model/diffusion.py:457)
+//     p      = posterior(q | E_t[i,j])                     (model/diffusion.py:351-406,463) -- 8-entry table
+//     E_s    = draw(p)                                     (model/diffusion.py:421)
+// and the draw goes straight into an upper-triangle bitmap: no (P,2) tensor, no pair index list, no dense N x N.
+//
+// MFMA mapping (v_mfma_f32_32x32x2_f32, exact f32): D[o][pair] += W1[o][k] * z[k][pair]; A = W1 rows (o), B = z
+// columns (32 consecutive j of one i).  With the pair on the MFMA column, one lane ends up holding 64 of the 128
+// hidden units of ONE pair, so the second layer is an in-lane dot product plus a single lane^32 exchange.
+// k order: step s feeds k=2s (lanes 0-31) and k=2s+1 (lanes 32-63); LDS rows are stored [even k | odd k] so a
+// lane's next four k-steps are one ds_read_b128.  hid[o] = fmaf chain over ascending k starting from b1[o]:
+// bit-identical to oracle gmo_pair_logits.
+//
+// Tiling: persistent workgroups (512 threads = 8 waves, 2 per SIMD) pull 64x64 tiles of the upper triangle from an
+// atomic counter.  W1 (64 KB) stays in LDS for the whole kernel; per tile the 64 h_i rows and 64 h_j rows are staged
+// (64 KB), i.e. 16 B of HBM/L2 traffic per pair against 33,408 FLOP: MFMA-bound (f32 matrix peak 157 TFLOP/s).
+#include "gm_common.h"
+
+namespace gm {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int HE = 128;
+constexpr int TILE = 64;          // TI == TJ
+constexpr int LDR = HE + 4;       // LDS row stride in floats: 132 -> ds_read_b128 of 16 consecutive rows is conflict-free
+constexpr int PAIR_THREADS = 512;
+
+struct PairArgs {
+    int64_t n;
+    const float* h;
+    const float* W1;
+    const float* b1;
+    const float* W2;
+    const float* b2;
+    const uint32_t* bits_t;
+    int64_t wpr;
+    float tab[8];
+    int64_t row_begin, row_end;
+    const float* u;
+    uint64_t seed;
+    uint32_t step;
+    uint32_t* out_upper;
+    float* logits_dbg;
+    float* post_dbg;
+    uint32_t* counter;
+    int nti, ntj, tjb;
+    int64_t ntiles;
+};
+
+__host__ __device__ __forceinline__ int64_t tile_prefix(int64_t ti, int64_t width) { return ti * width - ti * (ti - 1) / 2; }
+
+// store a float4 of 4 consecutive k into the [even k | odd k] row image
+__device__ __forceinline__ void put_split(float* row, int c4, float4 v) {
+    *reinterpret_cast<float2*>(row + 2 * c4) = make_float2(v.x, v.z);
+    *reinterpret_cast<float2*>(row + 64 + 2 * c4) = make_float2(v.y, v.w);
+}
+
+__global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const PairArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[(HE + 2 * TILE) * LDR + HE + 2 * HE + 4];
+    float* W1s = lds;
+    float* hIs = W1s + HE * LDR;
+    float* hJs = hIs + TILE * LDR;
+    float* b1s = hJs + TILE * LDR;
+    float* W2s = b1s + HE;
+    int* tile_s = reinterpret_cast<int*>(W2s + 2 * HE);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+
+    // ---- stage the pair MLP once per workgroup
+    for (int q = tid; q < HE * (HE / 4); q += PAIR_THREADS) {
+        const int o = q >> 5, c4 = q & 31;
+        put_split(W1s + o * LDR, c4, *reinterpret_cast<const float4*>(a.W1 + o * HE + 4 * c4));
+    }
+    if (tid < HE) b1s[tid] = a.b1[tid];
+    if (tid < 2 * HE) W2s[tid] = a.W2[tid];
+    const float b20 = a.b2[0], b21 = a.b2[1];
+    const float t0e0 = a.tab[0], t0e1 = a.tab[1], t1e0 = a.tab[2], t1e1 = a.tab[3];
+    const float t2e0 = a.tab[4], t2e1 = a.tab[5], t3e0 = a.tab[6], t3e1 = a.tab[7];
+    const int64_t width = (int64_t)a.ntj - a.tjb;
+
+    for (;;) {
+        __syncthreads();  // everyone is done with the previous tile's LDS image (and with tile_s)
+        if (tid == 0) *tile_s = (int)atomicAdd(a.counter, 1u);
+        __syncthreads();
+        const int64_t t = *tile_s;
+        if (t >= a.ntiles) break;
+        // decode t -> (ti, tj): largest ti with prefix(ti) <= t
+        int lo = 0, hi = a.nti - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (tile_prefix(mid, width) <= t) lo = mid; else hi = mid - 1;
+        }
+        const int ti = lo;
+        const int tj = a.tjb + ti + (int)(t - tile_prefix(ti, width));
+        const int64_t i0 = a.row_begin + (int64_t)ti * TILE;
+        const int64_t j0 = (int64_t)tj * TILE;
+
+        // ---- stage h rows of the tile: 2 x 64 rows x 32 float4
+        for (int q = tid; q < 2 * TILE * (HE / 4); q += PAIR_THREADS) {
+            const int which = q >> 11;             // 0: i rows, 1: j rows
+            const int r = (q >> 5) & (TILE - 1), c4 = q & 31;
+            const int64_t node = (which ? j0 : i0) + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (node < a.n) v = *reinterpret_cast<const float4*>(a.h + node * HE + 4 * c4);
+            put_split((which ? hJs : hIs) + r * LDR, c4, v);
+        }
+        __syncthreads();
+
+        // ---- each wave: 8 rows i, both 32-column halves of the tile per row
+        for (int rr = 0; rr < TILE / 8; ++rr) {
+            const int il = wv + 8 * rr;
+            const int64_t i = i0 + il;
+            if (i >= a.row_end || i >= a.n) continue;   // wave-uniform
+
+            floatx16 acc[2][4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bv = *reinterpret_cast<const float4*>(b1s + mt * 32 + 8 * g + 4 * half);
+                    acc[0][mt][4 * g + 0] = bv.x; acc[0][mt][4 * g + 1] = bv.y;
+                    acc[0][mt][4 * g + 2] = bv.z; acc[0][mt][4 * g + 3] = bv.w;
+                    acc[1][mt][4 * g + 0] = bv.x; acc[1][mt][4 * g + 1] = bv.y;
+                    acc[1][mt][4 * g + 2] = bv.z; acc[1][mt][4 * g + 3] = bv.w;
+                }
+
+            const float* wrow = W1s + l31 * LDR + 64 * half;
+            const float* hirow = hIs + il * LDR + 64 * half;
+            const float* hjrow = hJs + l31 * LDR + 64 * half;
+#pragma unroll 2
+            for (int q = 0; q < HE / 8; ++q) {
+                float4 w[4];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) w[mt] = *reinterpret_cast<const float4*>(wrow + mt * 32 * LDR + 4 * q);
+                const float4 hi4 = *reinterpret_cast<const float4*>(hirow + 4 * q);
+                const float4 ha = *reinterpret_cast<const float4*>(hjrow + 4 * q);
+                const float4 hb = *reinterpret_cast<const float4*>(hjrow + 32 * LDR + 4 * q);
+                const float hiv[4] = {hi4.x, hi4.y, hi4.z, hi4.w};
+                const float hav[4] = {ha.x, ha.y, ha.z, ha.w};
+                const float hbv[4] = {hb.x, hb.y, hb.z, hb.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float z0 = hiv[e] * hav[e];
+                    const float z1 = hiv[e] * hbv[e];
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        const float wv_ = e == 0 ? w[mt].x : e == 1 ? w[mt].y : e == 2 ? w[mt].z : w[mt].w;
+                        acc[0][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv_, z0, acc[0][mt], 0, 0, 0);
+                        acc[1][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv_, z1, acc[1][mt], 0, 0, 0);
+                    }
+                }
+            }
+
+            // ---- epilogue: second layer, softmax, posterior, draw, bitmap word
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float l0 = 0.0f, l1 = 0.0f;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int ob = mt * 32 + 8 * g + 4 * half;
+                        const float4 w0 = *reinterpret_cast<const float4*>(W2s + ob);
+                        const float4 w1 = *reinterpret_cast<const float4*>(W2s + HE + ob);
+                        const float w0v[4] = {w0.x, w0.y, w0.z, w0.w};
+                        const float w1v[4] = {w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) {
+                            float hid = acc[s][mt][4 * g + r4];
+                            hid = hid > 0.0f ? hid : 0.0f;
+                            l0 = __builtin_fmaf(hid, w0v[r4], l0);
+                            l1 = __builtin_fmaf(hid, w1v[r4], l1);
+                        }
+                    }
+                const float o0 = __shfl_xor(l0, 32), o1 = __shfl_xor(l1, 32);
+                const float s00 = half ? o0 : l0, s01 = half ? l0 : o0;   // (half-0 partial) + (half-1 partial)
+                const float s10 = half ? o1 : l1, s11 = half ? l1 : o1;
+                const float L0 = (s00 + s01) + b20;
+                const float L1 = (s10 + s11) + b21;
+
+                const int64_t j = j0 + 32 * s + l31;
+                const int64_t wi = 2 * (int64_t)tj + s;
+                const bool valid = (j > i) && (j < a.n);
+                uint32_t etw = 0;
+                if (wi < a.wpr) etw = a.bits_t[i * a.wpr + wi];
+                const bool e = (etw >> l31) & 1u;
+                float q0, q1;
+                softmax2(L0, L1, q0, q1);
+                const float a0 = q0 * (e ? t0e1 : t0e0);
+                const float c0 = q1 * (e ? t2e1 : t2e0);
+                const float a1 = q0 * (e ? t1e1 : t1e0);
+                const float c1 = q1 * (e ? t3e1 : t3e0);
+                const float p0 = a0 + c0, p1 = a1 + c1;
+                const int64_t rank = i * (2 * a.n - i - 1) / 2 + (j - i - 1);
+                float u;
+                if (a.u) u = valid ? a.u[rank] : 1.0f;
+                else u = u_pair(a.seed, a.step, (uint32_t)i, (uint32_t)j);
+                const bool bit = valid && draw2(u, p0, p1);
+                const unsigned long long m = __ballot(bit);
+                if (lane == 0 && wi < a.wpr) a.out_upper[i * a.wpr + wi] = (uint32_t)m;
+                if (valid && half == 0) {
+                    if (a.logits_dbg) { a.logits_dbg[2 * rank] = L0; a.logits_dbg[2 * rank + 1] = L1; }
+                    if (a.post_dbg) { a.post_dbg[2 * rank] = p0; a.post_dbg[2 * rank + 1] = p1; }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace gm
+
+using namespace gm;
+
+extern "C" int gm_pair_score_sample(int64_t n, int64_t hE, const float* h, const float* W1, const float* b1, const float* W2,
+                                    const float* b2, const uint32_t* bits_t, int64_t wpr, const float* tab, int64_t row_begin,
+                                    int64_t row_end, const float* u, uint64_t seed, uint32_t step, uint32_t* out_upper,
+                                    float* logits_dbg, float* post_dbg, void* workspace, gm_stream_t stream) {
+    GM_REQUIRE(hE == HE, "hidden_E=%lld is not supported: the pair kernel is built for hidden_E=128", (long long)hE);
+    GM_REQUIRE(n > 1 && n < (1ll << 31), "n out of range");
+    GM_REQUIRE(wpr >= (n + 31) / 32 && wpr % 4 == 0, "bad wpr");
+    GM_REQUIRE(h && W1 && b1 && W2 && b2 && bits_t && tab && out_upper && workspace, "null pointer");
+    GM_REQUIRE(aligned(h, 16) && aligned(W1, 16), "h and W1 must be 16-byte aligned");
+    GM_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= n, "bad row range [%lld,%lld)", (long long)row_begin,
+               (long long)row_end);
+    if (row_begin == row_end) return GM_OK;
+    hipStream_t s = as_stream(stream);
+    PairArgs a;
+    a.n = n; a.h = h; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.bits_t = bits_t; a.wpr = wpr;
+    for (int k = 0; k < 8; ++k) a.tab[k] = tab[k];
+    a.row_begin = row_begin; a.row_end = row_end; a.u = u; a.seed = seed; a.step = step;
+    a.out_upper = out_upper; a.logits_dbg = logits_dbg; a.post_dbg = post_dbg;
+    a.counter = static_cast<uint32_t*>(workspace);
+    // rows beyond the last one that has a partner (i = n-1) still get their (all-zero) words written
+    a.nti = (int)((row_end - row_begin + TILE - 1) / TILE);
+    a.ntj = (int)((n + TILE - 1) / TILE);
+    a.tjb = (int)(row_begin / TILE);
+    const int64_t width = (int64_t)a.ntj - a.tjb;
+    a.ntiles = tile_prefix(a.nti, width);
+    GM_REQUIRE(a.ntiles > 0 && a.ntiles < (1ll << 31), "tile count out of range");
+    int dev = 0, cus = 0;
+    GM_HIP(hipGetDevice(&dev));
+    GM_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    GM_REQUIRE(cus > 0, "no compute units reported");
+    GM_HIP(hipMemsetAsync(a.counter, 0, sizeof(uint32_t), s));
+    const unsigned grid = (unsigned)(a.ntiles < cus ? a.ntiles : cus);   // 137 KB of LDS: one workgroup per CU
+    hipLaunchKernelGGL(k_pair_score_sample, dim3(grid), dim3(PAIR_THREADS), 0, s, a);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}

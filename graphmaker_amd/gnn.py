@@ -1,0 +1,179 @@
+"""Denoiser networks with the reference's module tree, constructor arguments, forward signatures and state_dict
+keys (reference: model/gnn.py), executed by libgraphmaker_hip.so.
+
+The nn.Module objects here only HOLD parameters (so `load_state_dict` of a reference Sync/Async checkpoint works
+key for key, sample.py:64-65,78-79); every forward is a call into the HIP library.  Inference only: the kernels
+have no backward yet (training drop-in is the next scope row).
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import TowerDims
+
+__all__ = ["GNN", "LinkPredictor", "GNNAsymm", "GNNTower", "MLPTower"]
+
+
+def _update_block(in_f, out_f, dropout):
+    # Linear / ReLU / LayerNorm / Dropout, indices 0..3 as in model/gnn.py:27-38
+    return nn.Sequential(nn.Linear(in_f, out_f), nn.ReLU(), nn.LayerNorm(out_f), nn.Dropout(dropout))
+
+
+class _Layer(nn.Module):
+    """Parameter holder for GNNLayer (model/gnn.py:6-70) / MLPLayer (model/gnn.py:336-394)."""
+
+    def __init__(self, hidden_X, hidden_Y, hidden_t, dropout):
+        super().__init__()
+        self.update_X = _update_block(hidden_X + hidden_Y + hidden_t, hidden_X, dropout)
+        self.update_Y = _update_block(hidden_Y, hidden_Y, dropout)
+
+
+class _TowerBase(nn.Module):
+    _layers_attr = None
+    _is_mlp = False
+
+    def _build(self, num_attrs_X, num_classes_X, num_classes_Y, hidden_t, hidden_X, hidden_Y, out_size, num_layers,
+               dropout):
+        in_X = num_attrs_X * num_classes_X
+        self.num_attrs_X = num_attrs_X
+        self.num_classes_X = num_classes_X
+        self.mlp_in_t = nn.Sequential(nn.Linear(1, hidden_t), nn.ReLU(), nn.Linear(hidden_t, hidden_t), nn.ReLU())
+        self.mlp_in_X = nn.Sequential(nn.Linear(in_X, hidden_X), nn.ReLU(), nn.Linear(hidden_X, hidden_X), nn.ReLU())
+        self.emb_Y = nn.Embedding(num_classes_Y, hidden_Y)
+        setattr(self, self._layers_attr,
+                nn.ModuleList([_Layer(hidden_X, hidden_Y, hidden_t, dropout) for _ in range(num_layers)]))
+        hidden_cat = (num_layers + 1) * (hidden_X + hidden_Y) + hidden_t      # model/gnn.py:137
+        self.mlp_out = nn.Sequential(nn.Linear(hidden_cat, hidden_cat), nn.ReLU(), nn.Linear(hidden_cat, out_size))
+        self._dims = TowerDims(in_X=in_X, num_classes_Y=num_classes_Y, hidden_t=hidden_t, hidden_X=hidden_X,
+                               hidden_Y=hidden_Y, num_layers=num_layers, out_size=out_size, is_mlp=int(self._is_mlp))
+        self._ptr_key = None
+        self._ptr_arr = None
+        self._ws = None
+
+    # ---- C-ABI plumbing
+    def _ordered_params(self):
+        ps = [self.mlp_in_t[0].weight, self.mlp_in_t[0].bias, self.mlp_in_t[2].weight, self.mlp_in_t[2].bias,
+              self.mlp_in_X[0].weight, self.mlp_in_X[0].bias, self.mlp_in_X[2].weight, self.mlp_in_X[2].bias,
+              self.emb_Y.weight]
+        for layer in getattr(self, self._layers_attr):
+            ps += [layer.update_X[0].weight, layer.update_X[0].bias, layer.update_X[2].weight, layer.update_X[2].bias,
+                   layer.update_Y[0].weight, layer.update_Y[0].bias, layer.update_Y[2].weight, layer.update_Y[2].bias]
+        ps += [self.mlp_out[0].weight, self.mlp_out[0].bias, self.mlp_out[2].weight, self.mlp_out[2].bias]
+        return ps
+
+    def _param_ptrs(self):
+        ps = self._ordered_params()
+        key = tuple(p.data_ptr() for p in ps)
+        if key != self._ptr_key:
+            for p in ps:
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise TypeError("tower parameters must be contiguous float32")
+            self._ptr_arr = (C.c_void_p * len(ps))(*key)
+            self._ptr_key = key
+        return self._ptr_arr
+
+    def _workspace(self, n, device):
+        need = ops.tower_workspace_bytes(self._dims, n)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return self._ws
+
+    def _run(self, t_float, X_t_one_hot, Y_real, A_t, want_hcat=False):
+        if self.training and any(m.p > 0 for m in self.modules() if isinstance(m, nn.Dropout)):
+            raise NotImplementedError("graphmaker_amd towers run in eval mode only (dropout is not implemented)")
+        n = X_t_one_hot.shape[0]
+        X = X_t_one_hot if X_t_one_hot.is_contiguous() else X_t_one_hot.contiguous()
+        Y32 = Y_real if Y_real.dtype == torch.int32 else Y_real.to(torch.int32)
+        t = t_float.reshape(1).to(torch.float32)
+        return ops.tower_forward(self._dims, self._param_ptrs(), n, t, X, Y32.contiguous(), A_t,
+                                 self._workspace(n, X.device), want_hcat=want_hcat)
+
+
+class GNNTower(_TowerBase):
+    """model/gnn.py:72-176.  Same constructor and forward(t_float, X_t_one_hot, Y_real, A_t)."""
+    _layers_attr = "gnn_layers"
+
+    def __init__(self, num_attrs_X, num_classes_X, num_classes_Y, hidden_t, hidden_X, hidden_Y, out_size,
+                 num_gnn_layers, dropout, node_mode):
+        super().__init__()
+        self._build(num_attrs_X, num_classes_X, num_classes_Y, hidden_t, hidden_X, hidden_Y, out_size, num_gnn_layers,
+                    dropout)
+        self.node_mode = node_mode
+
+    @torch.no_grad()
+    def forward(self, t_float, X_t_one_hot, Y_real, A_t):
+        if not isinstance(A_t, ops.Adjacency):
+            raise TypeError("A_t must come from graphmaker_amd get_adj()/ops.adjacency_from_bitmap()")
+        out = self._run(t_float, X_t_one_hot, Y_real, A_t)
+        if self.node_mode:
+            return out.reshape(Y_real.size(0), self.num_attrs_X, -1)       # model/gnn.py:172
+        return out
+
+
+class MLPTower(_TowerBase):
+    """model/gnn.py:396-463.  forward(t_float, X_t_one_hot, Y_real)."""
+    _layers_attr = "mlp_layers"
+    _is_mlp = True
+
+    def __init__(self, num_attrs_X, num_classes_X, num_classes_Y, hidden_t, hidden_X, hidden_Y, num_mlp_layers,
+                 dropout):
+        super().__init__()
+        self._build(num_attrs_X, num_classes_X, num_classes_Y, hidden_t, hidden_X, hidden_Y,
+                    num_attrs_X * num_classes_X, num_mlp_layers, dropout)
+
+    @torch.no_grad()
+    def forward(self, t_float, X_t_one_hot, Y_real):
+        out = self._run(t_float, X_t_one_hot, Y_real, None)
+        return out.reshape(Y_real.size(0), self.num_attrs_X, -1)           # model/gnn.py:461
+
+
+class LinkPredictor(nn.Module):
+    """model/gnn.py:178-250.  forward(t_float, X_t_one_hot, Y_real, A_t, src, dst) -> (B, 2) logits."""
+
+    def __init__(self, num_attrs_X, num_classes_X, num_classes_Y, num_classes_E, hidden_t, hidden_X, hidden_Y, hidden_E,
+                 num_gnn_layers, dropout):
+        super().__init__()
+        self.gnn_encoder = GNNTower(num_attrs_X, num_classes_X, num_classes_Y, hidden_t, hidden_X, hidden_Y, hidden_E,
+                                    num_gnn_layers, dropout, node_mode=False)
+        self.mlp_out = nn.Sequential(nn.Linear(hidden_E, hidden_E), nn.ReLU(), nn.Linear(hidden_E, num_classes_E))
+
+    def pair_params(self):
+        return (self.mlp_out[0].weight, self.mlp_out[0].bias, self.mlp_out[2].weight, self.mlp_out[2].bias)
+
+    @torch.no_grad()
+    def forward(self, t_float, X_t_one_hot, Y_real, A_t, src, dst):
+        h = self.gnn_encoder(t_float, X_t_one_hot, Y_real, A_t)
+        z = ops.hadamard_gather(h, src.contiguous(), dst.contiguous())     # model/gnn.py:246
+        W1, b1, W2, b2 = self.pair_params()
+        return ops.linear(ops.linear(z, W1, b1, relu=True), W2, b2)        # model/gnn.py:248
+
+
+class GNN(nn.Module):
+    """model/gnn.py:252-334 (Sync denoiser: pred_X GNNTower + pred_E LinkPredictor)."""
+
+    def __init__(self, num_attrs_X, num_classes_X, num_classes_Y, num_classes_E, gnn_X_config, gnn_E_config):
+        super().__init__()
+        self.pred_X = GNNTower(num_attrs_X, num_classes_X, num_classes_Y, out_size=num_attrs_X * num_classes_X,
+                               node_mode=True, **gnn_X_config)
+        self.pred_E = LinkPredictor(num_attrs_X, num_classes_X, num_classes_Y, num_classes_E, **gnn_E_config)
+
+    def forward(self, t_float, X_t_one_hot, Y, A_t, batch_src, batch_dst):
+        logit_X = self.pred_X(t_float, X_t_one_hot, Y, A_t)
+        logit_E = self.pred_E(t_float, X_t_one_hot, Y, A_t, batch_src, batch_dst)
+        return logit_X, logit_E
+
+
+class GNNAsymm(nn.Module):
+    """model/gnn.py:465-550 (Async denoiser: pred_X MLPTower + pred_E LinkPredictor)."""
+
+    def __init__(self, num_attrs_X, num_classes_X, num_classes_Y, num_classes_E, mlp_X_config, gnn_E_config):
+        super().__init__()
+        self.pred_X = MLPTower(num_attrs_X, num_classes_X, num_classes_Y, **mlp_X_config)
+        self.pred_E = LinkPredictor(num_attrs_X, num_classes_X, num_classes_Y, num_classes_E, **gnn_E_config)
+
+    def forward(self, t_float_X, t_float_E, X_t_one_hot, Y, X_one_hot_2d, A_t, batch_src, batch_dst):
+        logit_X = self.pred_X(t_float_X, X_t_one_hot, Y)
+        logit_E = self.pred_E(t_float_E, X_one_hot_2d, Y, A_t, batch_src, batch_dst)
+        return logit_X, logit_E

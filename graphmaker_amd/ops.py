@@ -1,0 +1,231 @@
+"""Tensor-level wrappers of the C ABI (include/graphmaker_hip.h).  Each function is one library call on torch's
+current stream; torch supplies device memory and nothing else."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import F32, I32, I64, U32, U64, ptr, require, stream_ptr, words_per_row
+
+
+class Adjacency:
+    """What get_adj (model/diffusion.py:239-256) returns here: the row-normalised adjacency D^-1 A in CSR form with
+    implicit values 1/deg[row], plus the symmetric bitmap it was built from."""
+
+    def __init__(self, n, bits, rowptr, colidx):
+        self.n, self.bits, self.rowptr, self.colidx = n, bits, rowptr, colidx
+
+    @property
+    def shape(self):
+        return (self.n, self.n)
+
+    @property
+    def nnz(self):
+        return int(self.colidx.numel())
+
+    def __matmul__(self, H):
+        """A @ H (model/gnn.py:60-61)."""
+        return spmm_mean(self, H)
+
+
+# ------------------------------------------------------------------ adjacency
+def bitmap_from_dense(E):
+    require(E, torch.int64, "E")
+    n = E.shape[0]
+    wpr = words_per_row(n)
+    bits = torch.empty((n, wpr), dtype=torch.int32, device=E.device)
+    L.call("gm_bitmap_from_dense_i64", I64(n), I64(wpr), ptr(E), ptr(bits), stream_ptr())
+    return bits
+
+
+def dense_from_bitmap(bits, n):
+    require(bits, torch.int32, "bits")
+    E = torch.empty((n, n), dtype=torch.int64, device=bits.device)
+    L.call("gm_dense_i64_from_bitmap", I64(n), I64(bits.shape[1]), ptr(bits), ptr(E), stream_ptr())
+    return E
+
+
+def symmetrize_upper(upper, n, out=None):
+    require(upper, torch.int32, "upper")
+    sym = out if out is not None else torch.empty_like(upper)
+    L.call("gm_symmetrize_upper", I64(n), I64(upper.shape[1]), ptr(upper), ptr(sym), stream_ptr())
+    return sym
+
+
+def csr_from_bitmap(bits, n, upper_only=False, want_rows=False):
+    """(rowptr, colidx[, rows]) int32.  One host read of rowptr[n] sizes colidx."""
+    require(bits, torch.int32, "bits")
+    wpr = bits.shape[1]
+    rowptr = torch.empty(n + 1, dtype=torch.int32, device=bits.device)
+    L.call("gm_csr_rowptr", I64(n), I64(wpr), ptr(bits), I32(int(upper_only)), ptr(rowptr), stream_ptr())
+    nnz = int(rowptr[n].item())
+    colidx = torch.empty(max(nnz, 1), dtype=torch.int32, device=bits.device)
+    rows = torch.empty(max(nnz, 1), dtype=torch.int32, device=bits.device) if want_rows else None
+    L.call("gm_csr_fill", I64(n), I64(wpr), ptr(bits), I32(int(upper_only)), ptr(rowptr), I64(nnz), ptr(colidx),
+           ptr(rows), stream_ptr())
+    if want_rows:
+        return rowptr, colidx[:nnz], rows[:nnz]
+    return rowptr, colidx[:nnz]
+
+
+def adjacency_from_bitmap(bits, n):
+    rowptr, colidx = csr_from_bitmap(bits, n)
+    return Adjacency(n, bits, rowptr, colidx)
+
+
+def bitmap_from_upper_edges(n, ei, ej):
+    require(ei, torch.int32, "ei")
+    require(ej, torch.int32, "ej")
+    wpr = words_per_row(n)
+    bits = torch.empty((n, wpr), dtype=torch.int32, device=ei.device)
+    L.call("gm_bitmap_from_upper_edges", I64(n), I64(wpr), I64(ei.numel()), ptr(ei), ptr(ej), ptr(bits), stream_ptr())
+    return bits
+
+
+# ------------------------------------------------------------------ building blocks
+def spmm_mean(adj, H):
+    require(H, torch.float32, "H")
+    n, d = H.shape
+    out = torch.empty_like(H)
+    L.call("gm_spmm_mean", I64(n), ptr(adj.rowptr), ptr(adj.colidx), ptr(H), I64(d), I64(d), ptr(out), I64(d),
+           stream_ptr())
+    return out
+
+
+def linear(A, W, bias=None, relu=False):
+    require(A, torch.float32, "A")
+    require(W, torch.float32, "W")
+    M, K = A.shape
+    N = W.shape[0]
+    if W.shape[1] != K:
+        raise ValueError(f"linear: A is {tuple(A.shape)}, W is {tuple(W.shape)}")
+    out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    L.call("gm_linear", I64(M), I64(N), I64(K), ptr(A), I64(K), ptr(W), I64(K), ptr(bias), ptr(out), I64(N),
+           I32(int(relu)), stream_ptr())
+    return out
+
+
+def layernorm_(X, gamma, beta, eps=1e-5):
+    require(X, torch.float32, "X")
+    M, N = X.shape
+    L.call("gm_layernorm", I64(M), I64(N), ptr(X), I64(N), ptr(gamma), ptr(beta), F32(eps), stream_ptr())
+    return X
+
+
+def tower_workspace_bytes(dims, n):
+    nbytes = C.c_size_t()
+    L.call("gm_tower_workspace_bytes", C.byref(dims), I64(n), C.byref(nbytes))
+    return nbytes.value
+
+
+def tower_forward(dims, param_ptrs, n, t_float, X_one_hot, Y32, adj, workspace, out=None, want_hcat=False):
+    require(t_float, torch.float32, "t_float")
+    require(X_one_hot, torch.float32, "X_t_one_hot")
+    require(Y32, torch.int32, "Y")
+    if X_one_hot.shape != (n, dims.in_X):
+        raise ValueError(f"X_t_one_hot is {tuple(X_one_hot.shape)}, expected {(n, dims.in_X)}")
+    dev = X_one_hot.device
+    if out is None:
+        out = torch.empty((n, dims.out_size), dtype=torch.float32, device=dev)
+    hcat = torch.empty((n, dims.hidden_cat), dtype=torch.float32, device=dev) if want_hcat else None
+    rowptr = adj.rowptr if adj is not None else None
+    colidx = adj.colidx if adj is not None else None
+    L.call("gm_tower_forward", C.byref(dims), param_ptrs, I64(n), ptr(t_float), ptr(X_one_hot), ptr(Y32), ptr(rowptr),
+           ptr(colidx), ptr(out), ptr(hcat), ptr(workspace), C.c_size_t(workspace.numel()), stream_ptr())
+    return (out, hcat) if want_hcat else out
+
+
+def hadamard_gather(h, src, dst):
+    require(h, torch.float32, "h")
+    require(src, torch.int64, "src")
+    require(dst, torch.int64, "dst")
+    B, d = src.numel(), h.shape[1]
+    out = torch.empty((B, d), dtype=torch.float32, device=h.device)
+    L.call("gm_hadamard_gather", I64(B), I64(d), ptr(src), ptr(dst), ptr(h), I64(d), ptr(out), I64(d), stream_ptr())
+    return out
+
+
+# ------------------------------------------------------------------ structure denoiser
+def pair_score_sample(h, W1, b1, W2, b2, bits_t, tab, *, seed=0, step=0, u=None, row_begin=0, row_end=None,
+                      out_upper=None, workspace=None, want_debug=False):
+    """All pairs i<j of rows [row_begin,row_end): returns the upper-triangle bitmap of E_s
+    (and (P,2) logits / posteriors when want_debug)."""
+    require(h, torch.float32, "h")
+    require(bits_t, torch.int32, "bits_t")
+    n, hE = h.shape
+    wpr = bits_t.shape[1]
+    row_end = n if row_end is None else row_end
+    dev = h.device
+    if out_upper is None:
+        out_upper = torch.zeros((n, wpr), dtype=torch.int32, device=dev)
+    if workspace is None:
+        workspace = torch.empty(256, dtype=torch.uint8, device=dev)
+    P = n * (n - 1) // 2
+    lg = torch.zeros((P, 2), dtype=torch.float32, device=dev) if want_debug else None
+    po = torch.zeros((P, 2), dtype=torch.float32, device=dev) if want_debug else None
+    tab_host = (C.c_float * 8)(*[float(x) for x in tab])
+    if u is not None:
+        require(u, torch.float32, "u")
+        if u.numel() != P:
+            raise ValueError(f"u has {u.numel()} entries, expected P={P}")
+    L.call("gm_pair_score_sample", I64(n), I64(hE), ptr(h), ptr(W1), ptr(b1), ptr(W2), ptr(b2), ptr(bits_t), I64(wpr),
+           tab_host, I64(row_begin), I64(row_end), ptr(u), U64(seed), U32(step), ptr(out_upper), ptr(lg), ptr(po),
+           ptr(workspace), stream_ptr())
+    return (out_upper, lg, po) if want_debug else out_upper
+
+
+# ------------------------------------------------------------------ attributes
+def attr_posterior_sample(logits, x_t, tab, *, seed=0, step=0, u=None, want_onehot=True, want_debug=False):
+    require(logits, torch.float32, "logits")
+    require(x_t, torch.uint8, "x_t")
+    require(tab, torch.float32, "tab")
+    n, F = x_t.shape
+    dev = x_t.device
+    x_s = torch.empty_like(x_t)
+    oh = torch.empty((n, 2 * F), dtype=torch.float32, device=dev) if want_onehot else None
+    po = torch.empty((n, F, 2), dtype=torch.float32, device=dev) if want_debug else None
+    L.call("gm_attr_posterior_sample", I64(n), I64(F), ptr(logits), ptr(x_t), ptr(tab), ptr(u), U64(seed), U32(step),
+           ptr(x_s), ptr(oh), ptr(po), stream_ptr())
+    res = (x_s, oh)
+    return res + (po,) if want_debug else res
+
+
+def onehot_from_x(x):
+    require(x, torch.uint8, "x")
+    n, F = x.shape
+    oh = torch.empty((n, 2 * F), dtype=torch.float32, device=x.device)
+    L.call("gm_onehot_from_x", I64(n), I64(F), ptr(x), ptr(oh), stream_ptr())
+    return oh
+
+
+def x_from_onehot(oh):
+    require(oh, torch.float32, "X_one_hot")
+    n, F2 = oh.shape
+    x = torch.empty((n, F2 // 2), dtype=torch.uint8, device=oh.device)
+    L.call("gm_x_from_onehot", I64(n), I64(F2 // 2), ptr(oh), ptr(x), stream_ptr())
+    return x
+
+
+# ------------------------------------------------------------------ priors
+def prior_Y(n, Y_marginal, *, seed=0, u=None):
+    require(Y_marginal, torch.float32, "Y_marginal")
+    y = torch.empty(n, dtype=torch.int32, device=Y_marginal.device)
+    L.call("gm_prior_Y", I64(n), I32(Y_marginal.numel()), ptr(Y_marginal), ptr(u), U64(seed), ptr(y), stream_ptr())
+    return y
+
+
+def prior_X(n, X_marginal, *, seed=0, u=None):
+    require(X_marginal, torch.float32, "X_marginal")
+    F = X_marginal.shape[0]
+    x = torch.empty((n, F), dtype=torch.uint8, device=X_marginal.device)
+    oh = torch.empty((n, 2 * F), dtype=torch.float32, device=X_marginal.device)
+    L.call("gm_prior_X", I64(n), I64(F), ptr(X_marginal), ptr(u), U64(seed), ptr(x), ptr(oh), stream_ptr())
+    return x, oh
+
+
+def prior_E(n, p0, p1, device, *, seed=0, u=None):
+    wpr = words_per_row(n)
+    upper = torch.empty((n, wpr), dtype=torch.int32, device=device)
+    bits = torch.empty((n, wpr), dtype=torch.int32, device=device)
+    L.call("gm_prior_E", I64(n), I64(wpr), F32(p0), F32(p1), ptr(u), U64(seed), ptr(upper), ptr(bits), stream_ptr())
+    return bits

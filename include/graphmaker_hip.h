@@ -1,0 +1,134 @@
+/*
+ * include/graphmaker_hip.h -- C ABI of libgraphmaker_hip.so, the MI355X (gfx950) implementation of
+ * GraphMaker's reverse-diffusion denoising step.
+ *
+ * The reference (Graph-COM/GraphMaker) has no FFI of its own: its boundary is the Python API of
+ * model/diffusion.py + model/gnn.py.  Each entry point below names the reference lines it replaces; the
+ * Python host (graphmaker_amd/) keeps the reference's class/method signatures and calls these through ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the comment says "host"; the caller (torch-ROCm) owns all
+ *     memory, including outputs and workspaces; the library never allocates or frees device memory.
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it (no host sync).
+ *   - return value: 0 = ok, negative = GM_E_*; text via gm_last_error() (thread-local).
+ *   - adjacency state: symmetric bitmap, row i / word w holds nodes 32w..32w+31 (bit j&31), `wpr` 32-bit
+ *     words per row (multiple of 4, >= ceil(n/32)); padding bits are zero.
+ *   - attributes: uint8 x[v*F+f] in {0,1}; one-hot float layout oh[v*2F + 2f + c] (model/diffusion.py:232-235).
+ *   - draws: u in [0,1) = (philox word >> 8) * 2^-24; 2-class draw x = (u*(p0+p1) < p1).  With `u` == NULL
+ *     the kernels generate u themselves: Philox4x32-10, key = (seed lo, seed hi), counters
+ *        labels      (v>>2, 0, 0, 1)            word v&3
+ *        attributes  (lo(q), hi(q), step, 2)    word idx&3,  idx = f*n+v, q = idx>>2
+ *        E prior     (lo(q), hi(q), 0, 3)       word idx&3,  idx = i*n+j, q = idx>>2
+ *        E step      (j>>2, i, step, 4)         word j&3
+ *     With `u` != NULL it is a device array of host-supplied uniforms indexed: labels u[v]; attributes
+ *     u[f*n+v]; E prior u[i*n+j]; E step u[rank(i,j)], rank = row-major index of (i<j) as produced by
+ *     torch.triu_indices(n, n, offset=1) (model/diffusion.py:818-819).
+ */
+#ifndef GRAPHMAKER_HIP_H
+#define GRAPHMAKER_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GM_OK 0
+#define GM_E_INVALID (-1)    /* bad argument (shape, alignment, null) */
+#define GM_E_HIP (-2)        /* a HIP runtime call failed */
+#define GM_E_UNSUPPORTED (-3)
+
+typedef void* gm_stream_t;
+
+typedef struct {
+    int in_X;           /* num_attrs_X * num_classes_X = 2F                (model/gnn.py:112) */
+    int num_classes_Y;
+    int hidden_t, hidden_X, hidden_Y;
+    int num_layers;     /* num_gnn_layers / num_mlp_layers */
+    int out_size;       /* hidden_E (edge tower) or 2F (attribute towers) */
+    int is_mlp;         /* 0: GNNTower model/gnn.py:72-176; 1: MLPTower model/gnn.py:396-463 */
+} gm_tower_dims;
+
+int gm_version(void);
+const char* gm_last_error(void);
+/* host: number of compute units of the current device (grid sizing is internal; exposed for reports) */
+int gm_device_cus(int* cus);
+
+/* ---- adjacency: replaces the dense (N,N) int64 E_t of model/diffusion.py:422-424 and get_adj :239-256 ---- */
+int gm_bitmap_from_dense_i64(int64_t n, int64_t wpr, const int64_t* dense, uint32_t* bits, gm_stream_t stream);
+int gm_dense_i64_from_bitmap(int64_t n, int64_t wpr, const uint32_t* bits, int64_t* dense, gm_stream_t stream);
+/* sym = upper (bits j>=i of each row) mirrored below the diagonal; model/diffusion.py:208-210, 423-424 */
+int gm_symmetrize_upper(int64_t n, int64_t wpr, const uint32_t* upper, uint32_t* sym, gm_stream_t stream);
+/* get_adj (model/diffusion.py:252-256): E_t.nonzero() row-major -> CSR with ascending columns; the values
+ * 1/deg[row] stay implicit.  upper_only != 0 keeps only j>i (sorted upper edge list; `rows` then receives the
+ * row index of every entry, may be NULL).  Two calls because colidx is sized by rowptr[n]:
+ *   gm_csr_rowptr  : rowptr[0..n]           (workspace: none)
+ *   gm_csr_fill    : colidx[0..rowptr[n])   (caller read rowptr[n] to size it, or passes capacity >= nnz) */
+int gm_csr_rowptr(int64_t n, int64_t wpr, const uint32_t* bits, int upper_only, int32_t* rowptr, gm_stream_t stream);
+int gm_csr_fill(int64_t n, int64_t wpr, const uint32_t* bits, int upper_only, const int32_t* rowptr,
+                int64_t capacity, int32_t* colidx, int32_t* rows, gm_stream_t stream);
+/* edge list (i<j) -> symmetric bitmap (multi-GPU gather path; model/diffusion.py:423-424) */
+int gm_bitmap_from_upper_edges(int64_t n, int64_t wpr, int64_t m, const int32_t* ei, const int32_t* ej,
+                               uint32_t* bits, gm_stream_t stream);
+
+/* ---- message passing: A @ H with A = D^-1 A (model/gnn.py:60-61, model/diffusion.py:255-256) ---- */
+int gm_spmm_mean(int64_t n, const int32_t* rowptr, const int32_t* colidx, const float* H, int64_t ldh, int64_t d,
+                 float* out, int64_t ldo, gm_stream_t stream);
+
+/* ---- nn.Linear (+ReLU) and nn.LayerNorm as used by model/gnn.py:27-38,116-126,138-142,227-231 ----
+ * C[M,N] (ldc) = act(A[M,K] (lda) @ W[N,K]^T (ldw) + bias[N]);  f32 MFMA, k-ascending accumulation. */
+int gm_linear(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw,
+              const float* bias, float* C, int64_t ldc, int relu, gm_stream_t stream);
+int gm_layernorm(int64_t M, int64_t N, float* X, int64_t ldx, const float* gamma, const float* beta, float eps,
+                 gm_stream_t stream);
+
+/* ---- towers: GNNTower.forward model/gnn.py:146-176, MLPTower.forward model/gnn.py:440-463 ----
+ * params: HOST array of DEVICE pointers in state_dict order:
+ *   mlp_in_t.{0,2}.{weight,bias}, mlp_in_X.{0,2}.{weight,bias}, emb_Y.weight,
+ *   per layer: update_X.0.{weight,bias}, update_X.2.{weight,bias}, update_Y.0.{weight,bias}, update_Y.2.{weight,bias},
+ *   mlp_out.{0,2}.{weight,bias}                                   (9 + 8*num_layers + 4 pointers)
+ * t_float: device pointer to one float (the reference passes a (1,) tensor, model/diffusion.py:860).
+ * out: (n, out_size) row-major.  hcat_out: optional (n, hidden_cat) copy of the concatenated hidden state. */
+int gm_tower_workspace_bytes(const gm_tower_dims* dims, int64_t n, size_t* bytes);
+int gm_tower_forward(const gm_tower_dims* dims, const float* const* params, int64_t n, const float* t_float,
+                     const float* X_one_hot, const int32_t* Y, const int32_t* rowptr, const int32_t* colidx,
+                     float* out, float* hcat_out, void* workspace, size_t workspace_bytes, gm_stream_t stream);
+
+/* z[b] = h[src[b]] * h[dst[b]] for an explicit pair list: LinkPredictor.forward on a caller-chosen batch
+ * (model/gnn.py:246); followed by two gm_linear calls it gives the (B,2) logits of model/gnn.py:248. */
+int gm_hadamard_gather(int64_t B, int64_t d, const int64_t* src, const int64_t* dst, const float* h, int64_t ldh,
+                       float* out, int64_t ldo, gm_stream_t stream);
+
+/* ---- structure denoiser: the loop of get_E_t (model/diffusion.py:444-470) over ALL pairs i<j of rows
+ * [row_begin,row_end): pair MLP (model/gnn.py:246-248) -> softmax (:457) -> posterior (:351-406, as the table
+ * `tab`) -> draw (:421).  Nothing P-sized is stored: the result is the upper-triangle bitmap `out_upper`
+ * (rows [row_begin,row_end), words w >= (row>>5) are written).
+ * hE must be 128.  tab: HOST pointer to 8 floats tab[(i*2+k)*2+e] = Q_t[k][e]*Qbar_s[i][k]/Qbar_t[i][e].
+ * workspace: >= 256 bytes (tile counter).  logits_dbg/post_dbg: optional (P,2) arrays indexed by rank. */
+int gm_pair_score_sample(int64_t n, int64_t hE, const float* h, const float* W1, const float* b1, const float* W2,
+                         const float* b2, const uint32_t* bits_t, int64_t wpr, const float* tab,
+                         int64_t row_begin, int64_t row_end, const float* u, uint64_t seed, uint32_t step,
+                         uint32_t* out_upper, float* logits_dbg, float* post_dbg, void* workspace,
+                         gm_stream_t stream);
+
+/* ---- attribute posterior + draw: model/diffusion.py:879-895 + sample_X :214-237 ----
+ * logits (n,F,2); tab device (F,8) per-attribute posterior tables; x_s (n,F) uint8; onehot_out optional (n,2F). */
+int gm_attr_posterior_sample(int64_t n, int64_t F, const float* logits, const uint8_t* x_t, const float* tab,
+                             const float* u, uint64_t seed, uint32_t step, uint8_t* x_s, float* onehot_out,
+                             float* post_dbg, gm_stream_t stream);
+int gm_onehot_from_x(int64_t n, int64_t F, const uint8_t* x, float* onehot, gm_stream_t stream);
+int gm_x_from_onehot(int64_t n, int64_t F, const float* onehot, uint8_t* x, gm_stream_t stream);
+
+/* ---- priors: model/diffusion.py:831-844 (sample_E :188-212 keeps the diagonal) ---- */
+int gm_prior_Y(int64_t n, int C, const float* Y_marginal, const float* u, uint64_t seed, int32_t* y,
+               gm_stream_t stream);
+int gm_prior_X(int64_t n, int64_t F, const float* X_marginal, const float* u, uint64_t seed, uint8_t* x,
+               float* onehot_out, gm_stream_t stream);
+/* upper_ws: scratch bitmap (n*wpr words); bits: symmetric result incl. diagonal draws */
+int gm_prior_E(int64_t n, int64_t wpr, float p0, float p1, const float* u, uint64_t seed, uint32_t* upper_ws,
+               uint32_t* bits, gm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

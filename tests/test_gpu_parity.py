@@ -1,0 +1,340 @@
+"""GPU parity tests: the HIP library (through its C ABI, graphmaker_amd/_lib.py) against the CPU oracle on the same
+seeded inputs, and against the fixtures generated from the reference (tests/golden/).
+
+Bars (SURVEY.md 8 / BASELINE.json north_star):
+  * CSR construction, bitmaps, priors, draws: bit-exact.
+  * fp32 logits / posteriors vs the REFERENCE fixtures: atol 2e-5 (logits), 2e-6 (posteriors), rtol 1e-5.
+  * vs the ORACLE the kernels use the same accumulation orders, so floats are compared bit for bit (EXACT=True).
+"""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+import oracle_lib as orc
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_ATOL, POST_ATOL, RTOL, KNIFE = 2e-5, 2e-6, 1e-5, 1e-5
+EXACT = True   # HIP vs oracle: identical accumulation orders -> identical bits
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _ops():
+    from graphmaker_amd import ops
+    return ops
+
+
+def t_(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def bits_t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
+
+
+def bits_np(t):
+    return t.cpu().numpy().view(np.uint32)
+
+
+def check_float(got, want, atol, what):
+    got = got.cpu().numpy() if isinstance(got, torch.Tensor) else got
+    np.testing.assert_allclose(got, want, atol=atol, rtol=RTOL, err_msg=what)
+    if EXACT:
+        nbad = int((got.view(np.uint32) != np.ascontiguousarray(want, np.float32).view(np.uint32)).sum())
+        assert nbad == 0, f"{what}: {nbad} of {got.size} values differ in their bits from the oracle"
+
+
+def random_sym_bits(n, density, seed):
+    rs = np.random.RandomState(seed)
+    d = np.triu((rs.uniform(size=(n, n)) < density), 1).astype(np.int64)
+    d = d + d.T
+    return d, orc.bitmap_from_dense(d)
+
+
+# ------------------------------------------------------------------ adjacency / CSR : bit-exact
+@pytest.mark.parametrize("n,density", [(2, 1.0), (31, 0.2), (64, 0.1), (67, 0.0), (257, 0.05), (1000, 0.01)])
+def test_bitmap_and_csr_bit_exact(dev, n, density):
+    ops = _ops()
+    d, ref_bits = random_sym_bits(n, density, n)
+    bits = ops.bitmap_from_dense(t_(d, dev))
+    np.testing.assert_array_equal(bits_np(bits), ref_bits)
+    np.testing.assert_array_equal(ops.dense_from_bitmap(bits, n).cpu().numpy(), d)
+    rowptr, colidx = ops.csr_from_bitmap(bits, n)
+    rp, ci = orc.csr_from_bitmap(ref_bits, n)
+    np.testing.assert_array_equal(rowptr.cpu().numpy(), rp)
+    np.testing.assert_array_equal(colidx.cpu().numpy(), ci)
+    # sorted upper edge list + rebuild
+    rp_u, cj, ri = ops.csr_from_bitmap(bits, n, upper_only=True, want_rows=True)
+    ei, ej = orc.upper_edges_from_bitmap(ref_bits, n)
+    np.testing.assert_array_equal(ri.cpu().numpy(), ei)
+    np.testing.assert_array_equal(cj.cpu().numpy(), ej)
+    if len(ei):
+        back = ops.bitmap_from_upper_edges(n, ri.contiguous(), cj.contiguous())
+        np.testing.assert_array_equal(bits_np(back), ref_bits)
+
+
+@pytest.mark.parametrize("n", [2, 33, 64, 200, 777])
+def test_symmetrize_bit_exact(dev, n):
+    ops = _ops()
+    rs = np.random.RandomState(n)
+    wpr = orc.words_per_row(n)
+    # garbage below the diagonal and in padding words must be ignored / cleared
+    upper = rs.randint(0, 2 ** 32, size=(n, wpr), dtype=np.uint64).astype(np.uint32)
+    dense_u = np.zeros((n, n), np.int64)
+    for i in range(n):
+        for j in range(i, n):
+            dense_u[i, j] = (upper[i, j >> 5] >> (j & 31)) & 1
+    want = np.triu(dense_u) + np.triu(dense_u, 1).T
+    sym = ops.symmetrize_upper(bits_t(upper, dev), n)
+    np.testing.assert_array_equal(bits_np(sym), orc.bitmap_from_dense(want))
+
+
+# ------------------------------------------------------------------ building blocks
+@pytest.mark.parametrize("n,d,density", [(67, 48, 0.1), (300, 576, 0.02), (300, 64, 0.0), (129, 20, 0.3)])
+def test_spmm_mean(dev, n, d, density):
+    ops = _ops()
+    _, ref_bits = random_sym_bits(n, density, 7 * n + d)
+    rp, ci = orc.csr_from_bitmap(ref_bits, n)
+    H = np.random.RandomState(d).normal(size=(n, d)).astype(np.float32)
+    adj = ops.adjacency_from_bitmap(bits_t(ref_bits, dev), n)
+    check_float(ops.spmm_mean(adj, t_(H, dev)), orc.spmm_mean(rp, ci, H), 1e-6, "spmm")
+
+
+@pytest.mark.parametrize("M,N,K,relu,bias", [(1, 16, 1, True, True), (67, 32, 22, True, True), (200, 304, 304, True, True),
+                                             (130, 128, 152, False, True), (257, 40, 131, False, False),
+                                             (300, 1534, 1744, False, True)])
+def test_linear(dev, M, N, K, relu, bias):
+    ops = _ops()
+    rs = np.random.RandomState(M + N + K)
+    A = rs.normal(size=(M, K)).astype(np.float32)
+    W = (rs.normal(size=(N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rs.normal(size=N).astype(np.float32) if bias else None
+    got = ops.linear(t_(A, dev), t_(W, dev), t_(b, dev) if bias else None, relu=relu)
+    check_float(got, orc.linear(A, W, b, relu), 1e-5, f"linear {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("M,N", [(5, 64), (67, 512), (33, 1024), (10, 100)])
+def test_layernorm(dev, M, N):
+    ops = _ops()
+    rs = np.random.RandomState(M * N)
+    X = (rs.normal(size=(M, N)) * 3 + 1).astype(np.float32)
+    g = rs.normal(size=N).astype(np.float32)
+    b = rs.normal(size=N).astype(np.float32)
+    got = ops.layernorm_(t_(X, dev), t_(g, dev), t_(b, dev))
+    check_float(got, orc.layernorm(X, g, b), 1e-5, "layernorm")
+    ref = torch.nn.functional.layer_norm(torch.from_numpy(X), (N,), torch.from_numpy(g), torch.from_numpy(b)).numpy()
+    np.testing.assert_allclose(got.cpu().numpy(), ref, atol=2e-5, rtol=RTOL)
+
+
+# ------------------------------------------------------------------ model-level: fixtures from the reference
+def _models(name, dev):
+    import graphmaker_amd as gm
+    cfg = gu.CASES[name]
+    Xm, Ym, Em = gu.marginals(cfg)
+    sdX, sdE = gu.make_checkpoint(cfg)
+    kw = dict(X_marginal=t_(Xm, dev), Y_marginal=t_(Ym, dev), E_marginal=t_(Em, dev), num_nodes=cfg["N"])
+    if cfg["variant"] == "Sync":
+        model = gm.ModelSync(T=cfg["T"], gnn_X_config=cfg["gnn_X"], gnn_E_config=cfg["gnn_E"], **kw)
+    else:
+        model = gm.ModelAsync(T_X=cfg["T_X"], T_E=cfg["T_E"], mlp_X_config=cfg["mlp_X"], gnn_E_config=cfg["gnn_E"], **kw)
+    model.graph_encoder.pred_X.load_state_dict({k: torch.from_numpy(v) for k, v in sdX.items()})
+    model.graph_encoder.pred_E.load_state_dict({k: torch.from_numpy(v) for k, v in sdE.items()})
+    model = model.to(dev).eval()
+    towerX = orc.Tower.from_state_dict(sdX, is_mlp=(cfg["variant"] == "Async"))
+    towerE = orc.Tower.from_state_dict(sdE, is_mlp=False, prefix="gnn_encoder.")
+    pair = orc.PairMLP(sdE["mlp_out.0.weight"], sdE["mlp_out.0.bias"], sdE["mlp_out.2.weight"], sdE["mlp_out.2.bias"])
+    return cfg, gu.load_golden(name), model, towerX, towerE, pair, (Xm, Ym, Em)
+
+
+def _bits_from_nz(nz, n):
+    d = np.zeros((n, n), np.int64)
+    d[nz[:, 0], nz[:, 1]] = 1
+    return orc.bitmap_from_dense(d), d
+
+
+@pytest.mark.parametrize("name", list(gu.CASES))
+def test_priors_bit_exact(dev, name):
+    ops = _ops()
+    cfg, g, model, *_, (Xm, Ym, Em) = _models(name, dev)
+    N, F, seed = cfg["N"], cfg["F"], cfg["seed"]
+    np.testing.assert_array_equal(ops.prior_Y(N, t_(Ym, dev), seed=seed).cpu().numpy(), g["Y"])
+    bits = ops.prior_E(N, float(Em[0]), float(Em[1]), dev, seed=seed)
+    ref_bits, _ = _bits_from_nz(g["E_T_nz"], N)
+    np.testing.assert_array_equal(bits_np(bits), ref_bits)
+    x, oh = ops.prior_X(N, t_(Xm, dev), seed=seed)
+    np.testing.assert_array_equal(x.cpu().numpy(), orc.prior_X(N, Xm, seed=seed))
+    np.testing.assert_array_equal(oh.cpu().numpy(), orc.onehot_from_x(x.cpu().numpy()))
+    # host-supplied uniforms == in-kernel Philox
+    bits_u = ops.prior_E(N, float(Em[0]), float(Em[1]), dev, u=t_(orc.uniform_E_prior(seed, N), dev))
+    np.testing.assert_array_equal(bits_np(bits_u), ref_bits)
+    x_u, _ = ops.prior_X(N, t_(Xm, dev), u=t_(orc.uniform_X(seed, 0, N, F), dev))
+    np.testing.assert_array_equal(x_u.cpu().numpy(), x.cpu().numpy())
+    y_u = ops.prior_Y(N, t_(Ym, dev), u=t_(orc.uniform_Y(seed, N), dev))
+    np.testing.assert_array_equal(y_u.cpu().numpy(), g["Y"])
+
+
+@pytest.mark.parametrize("name", list(gu.CASES))
+def test_structure_step_vs_reference_and_oracle(dev, name):
+    ops = _ops()
+    cfg, g, model, towerX, towerE, pair, (Xm, Ym, Em) = _models(name, dev)
+    N, seed = cfg["N"], cfg["seed"]
+    sync = cfg["variant"] == "Sync"
+    T = cfg["T"] if sync else cfg["T_E"]
+    ns = model.noise_schedule if sync else model.noise_schedule_E
+    Y32 = t_(g["Y"], dev)
+    pred_E = model.graph_encoder.pred_E
+    for t in range(T, 0, -1):
+        ref_bits, dense = _bits_from_nz(g[f"e{t}_E_in_nz"], N)
+        # get_adj on the reference's dense E_t: CSR bit-exact vs the reference's COO
+        A_t = model.get_adj(t_(dense, dev))
+        row = np.repeat(np.arange(N, dtype=np.int32), np.diff(A_t.rowptr.cpu().numpy()))
+        np.testing.assert_array_equal(row, g[f"e{t}_A_row"])
+        np.testing.assert_array_equal(A_t.colidx.cpu().numpy(), g[f"e{t}_A_col"])
+        # encoder
+        X_oh = t_(orc.onehot_from_x(g[f"e{t}_X_in"]), dev)
+        t_float = torch.tensor([t / T], dtype=torch.float32, device=dev)
+        h = pred_E.gnn_encoder(t_float, X_oh, Y32, A_t)
+        np.testing.assert_allclose(h.cpu().numpy(), g[f"e{t}_h"], atol=LOGIT_ATOL, rtol=RTOL)
+        rp, ci = orc.csr_from_bitmap(ref_bits, N)
+        check_float(h, towerE.forward(np.float32(t / T), X_oh.cpu().numpy(), g["Y"], rp, ci), LOGIT_ATOL, "edge tower")
+        # LinkPredictor.forward on an explicit batch (reference signature)
+        i, j = np.triu_indices(N, 1)
+        sel = np.random.RandomState(t).choice(len(i), size=min(500, len(i)), replace=False)
+        lg_b = pred_E(t_float, X_oh, Y32, A_t, t_(j[sel], dev), t_(i[sel], dev))
+        np.testing.assert_allclose(lg_b.cpu().numpy(), g[f"e{t}_pair_logits"][sel], atol=LOGIT_ATOL, rtol=RTOL)
+        # all-pairs kernel fed the REFERENCE's h, host-supplied uniforms
+        a_t, ab_s, ab_t = ns.alphas_host[t], ns.alpha_bars_host[t - 1], ns.alpha_bars_host[t]
+        tab = model.transition.table_E(a_t, ab_s, ab_t)
+        u = orc.uniform_E(seed, t, N)
+        W1, b1, W2, b2 = pred_E.pair_params()
+        h_ref = t_(g[f"e{t}_h"], dev)
+        up, lg, po = ops.pair_score_sample(h_ref, W1, b1, W2, b2, bits_t(ref_bits, dev), tab, u=t_(u, dev), want_debug=True)
+        np.testing.assert_allclose(lg.cpu().numpy(), g[f"e{t}_pair_logits"], atol=LOGIT_ATOL, rtol=RTOL)
+        np.testing.assert_allclose(po.cpu().numpy(), g[f"e{t}_E_prob"], atol=POST_ATOL, rtol=RTOL)
+        o_up, o_lg, o_po = orc.pair_score_sample(N, g[f"e{t}_h"], pair, ref_bits, tab, u=u, want_debug=True)
+        check_float(lg, o_lg, LOGIT_ATOL, "pair logits")
+        check_float(po, o_po, POST_ATOL, "pair posteriors")
+        sym = ops.symmetrize_upper(up, N)
+        np.testing.assert_array_equal(bits_np(sym), orc.symmetrize_upper(o_up, N))        # draws: bit-exact vs oracle
+        # in-kernel Philox == host-supplied uniforms
+        up2 = ops.pair_score_sample(h_ref, W1, b1, W2, b2, bits_t(ref_bits, dev), tab, seed=seed, step=t)
+        np.testing.assert_array_equal(bits_np(ops.symmetrize_upper(up2, N)), bits_np(sym))
+        # vs the reference's sampled adjacency: identical (a difference would have to sit on the threshold)
+        want_bits, _ = _bits_from_nz(g[f"e{t}_E_out_nz"], N)
+        if not np.array_equal(bits_np(sym), want_bits):
+            mine = (bits_np(up)[i, j >> 5] >> (j & 31)) & 1
+            ref = (want_bits[i, j >> 5] >> (j & 31)) & 1
+            idx = np.flatnonzero(mine != ref)
+            p = g[f"e{t}_E_prob"]
+            far = [r for r in idx if abs(u[r] * (p[r, 0] + p[r, 1]) - p[r, 1]) > KNIFE]
+            assert not far, f"{len(far)} draws differ away from their threshold"
+            pytest.fail(f"{len(idx)} threshold-level flips vs the reference (not expected on these fixtures)")
+
+
+@pytest.mark.parametrize("name", list(gu.CASES))
+def test_attribute_step_vs_reference_and_oracle(dev, name):
+    ops = _ops()
+    cfg, g, model, towerX, towerE, pair, (Xm, Ym, Em) = _models(name, dev)
+    N, F, seed = cfg["N"], cfg["F"], cfg["seed"]
+    sync = cfg["variant"] == "Sync"
+    T = cfg["T"] if sync else cfg["T_X"]
+    ns = model.noise_schedule if sync else model.noise_schedule_X
+    Y32 = t_(g["Y"], dev)
+    for t in range(T, 0, -1):
+        x_in = g[f"e{t}_X_in"] if sync else g[f"x{t}_X_in"]
+        X_oh = t_(orc.onehot_from_x(x_in), dev)
+        t_float = torch.tensor([t / T], dtype=torch.float32, device=dev)
+        if sync:
+            ref_bits, dense = _bits_from_nz(g[f"e{t}_E_in_nz"], N)
+            A_t = model.get_adj(t_(dense, dev))
+            logits = model.graph_encoder.pred_X(t_float, X_oh, Y32, A_t)
+            rp, ci = orc.csr_from_bitmap(ref_bits, N)
+            o_logits = towerX.forward(np.float32(t / T), X_oh.cpu().numpy(), g["Y"], rp, ci)
+        else:
+            logits = model.graph_encoder.pred_X(t_float, X_oh, Y32)
+            o_logits = towerX.forward(np.float32(t / T), X_oh.cpu().numpy(), g["Y"])
+        assert tuple(logits.shape) == (N, F, 2)
+        np.testing.assert_allclose(logits.cpu().numpy(), g[f"x{t}_X_logits"], atol=LOGIT_ATOL, rtol=RTOL)
+        check_float(logits.reshape(N, 2 * F), o_logits, LOGIT_ATOL, "attribute tower")
+        tab = model.transition.table_X(ns.alphas_host[t], ns.alpha_bars_host[t - 1], ns.alpha_bars_host[t])
+        u = orc.uniform_X(seed, t, N, F)
+        ref_logits = t_(g[f"x{t}_X_logits"].reshape(N, 2 * F), dev)
+        x_s, oh, po = ops.attr_posterior_sample(ref_logits, t_(x_in, dev), t_(tab, dev), u=t_(u, dev), want_debug=True)
+        ref_prob = np.transpose(g[f"x{t}_X_prob"], (1, 0, 2))
+        np.testing.assert_allclose(po.cpu().numpy(), ref_prob, atol=POST_ATOL, rtol=RTOL)
+        o_x, o_po = orc.attr_posterior_sample(g[f"x{t}_X_logits"], x_in, tab, u=u, want_debug=True)
+        check_float(po, o_po, POST_ATOL, "attribute posteriors")
+        np.testing.assert_array_equal(x_s.cpu().numpy(), o_x)
+        np.testing.assert_array_equal(oh.cpu().numpy(), orc.onehot_from_x(o_x))
+        x_p, _ = ops.attr_posterior_sample(ref_logits, t_(x_in, dev), t_(tab, dev), seed=seed, step=t)
+        np.testing.assert_array_equal(x_p.cpu().numpy(), o_x)
+        np.testing.assert_array_equal(x_s.cpu().numpy(), g[f"x{t}_X_out"])
+
+
+@pytest.mark.parametrize("name", ["sync_small", "sync_mid", "async_mid"])
+def test_sample_matches_reference_trajectory(dev, name):
+    cfg, g, model, *_ = _models(name, dev)
+    N, F = cfg["N"], cfg["F"]
+    X, Y1h, E = model.sample(seed=cfg["seed"])
+    assert tuple(X.shape) == (F, N, 2) and X.dtype == torch.float32            # model/diffusion.py:810-815
+    assert tuple(Y1h.shape) == (N, cfg["C"]) and tuple(E.shape) == (N, N) and E.dtype == torch.int64
+    np.testing.assert_array_equal(Y1h.argmax(1).cpu().numpy(), g["final_Y"])
+    np.testing.assert_array_equal(X[:, :, 1].T.cpu().numpy().astype(np.uint8), g["final_X"])
+    want = np.zeros((N, N), np.int64)
+    want[g["final_E_nz"][:, 0], g["final_E_nz"][:, 1]] = 1
+    np.testing.assert_array_equal(E.cpu().numpy(), want)
+    assert torch.equal(E, E.T) and int(E.diagonal().sum()) == 0
+    # the sparse return carries the same edges
+    _, _, el = model.sample(seed=cfg["seed"], dense=False)
+    iu, ju = np.nonzero(np.triu(want, 1))
+    np.testing.assert_array_equal(el.cpu().numpy(), np.stack([iu, ju]))
+
+
+# ------------------------------------------------------------------ larger sizes: properties + oracle on a slice
+def test_pair_kernel_large_against_oracle_rows_and_sharding(dev):
+    ops = _ops()
+    n = 2500                                     # 40 x 40 tiles, ragged last tile
+    rs = np.random.RandomState(3)
+    h = (rs.normal(size=(n, 128)) * 0.5).astype(np.float32)
+    W1 = (rs.normal(size=(128, 128)) / 11).astype(np.float32)
+    b1 = rs.normal(size=128).astype(np.float32) * 0.1
+    W2 = (rs.normal(size=(2, 128)) / 11).astype(np.float32)
+    b2 = np.array([1.0, -1.0], np.float32)
+    _, bits = random_sym_bits(n, 0.01, 5)
+    tab = orc.posterior_table_E([0.99, 0.01], 0.58304191, 0.84701216, 0.49384356)
+    args = [t_(x, dev) for x in (h, W1, b1, W2, b2)]
+    full = ops.pair_score_sample(*args, bits_t(bits, dev), tab, seed=99, step=2)
+    sym = ops.symmetrize_upper(full, n)
+    # determinism
+    again = ops.symmetrize_upper(ops.pair_score_sample(*args, bits_t(bits, dev), tab, seed=99, step=2), n)
+    assert torch.equal(sym, again)
+    # row-block sharding (multi-GPU decomposition): rows [0,a) u [a,b) u [b,n) reproduce the full result
+    out = torch.zeros_like(full)
+    for r0, r1 in [(0, 700), (700, 1801), (1801, n)]:
+        ops.pair_score_sample(*args, bits_t(bits, dev), tab, seed=99, step=2, row_begin=r0, row_end=r1, out_upper=out)
+    assert torch.equal(ops.symmetrize_upper(out, n), sym)
+    # oracle on three row bands (first, middle across tile borders, last)
+    pair = orc.PairMLP(W1, b1, W2, b2)
+    got = bits_np(full)
+    for r0, r1 in [(0, 3), (1278, 1283), (n - 3, n)]:
+        want = orc.pair_score_sample(n, h, pair, bits, tab, seed=99, step=2, row_begin=r0, row_end=r1)
+        for i in range(r0, r1):
+            w0 = i >> 5
+            mask0 = np.uint32(0xFFFFFFFF) << np.uint32((i & 31) + 1) if (i & 31) < 31 else np.uint32(0)
+            np.testing.assert_array_equal(got[i, w0] & mask0, want[i, w0])
+            np.testing.assert_array_equal(got[i, w0 + 1:(n + 31) // 32], want[i, w0 + 1:(n + 31) // 32])
+    dense = ops.dense_from_bitmap(sym, n)
+    assert torch.equal(dense, dense.T) and int(dense.diagonal().sum()) == 0
+
+
+def test_no_fallback_on_cpu_tensors():
+    from graphmaker_amd import ops
+    from graphmaker_amd._lib import GraphMakerHipError
+    with pytest.raises(GraphMakerHipError):
+        ops.bitmap_from_dense(torch.zeros((4, 4), dtype=torch.int64))
