@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- denoising steps/s + pair-scores/s of one GraphMaker-Sync reverse step at amazon_computer shapes.
+
+    python bench.py --gpus N --steps K --warmup W
+(for N > 1 the driver launches it under torch.distributed.run, one rank per GPU over RCCL).
+
+A "step" is the body of the loop at model/diffusion.py:847-896 on synthetic, dataset-shaped input that is already
+resident in HBM: CSR build from the E_t bitmap, edge tower, all-pairs scoring + posterior + draw, symmetrise, node
+tower, attribute posterior + draw.  The input state of every timed step is the same prior draw (E_T at the dataset's
+density 2.6e-3, X_T, Y_0) at t = T, so the sparse part of the work is pinned while nothing is skipped or cached.
+Output: ONE JSON line on rank 0 (contract in the task statement) with two extra objects, `roofline` (the pair kernel
+against the f32 MFMA peak) and `cpu_baseline` (the CPU oracle on the box's host cores, a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# amazon_computer: data.py / SURVEY.md section 8 table; hyper-parameters configs/amazon_computer/train_Sync.yaml
+WORKLOAD = dict(name="amazon_computer", N=13752, F=767, C=10, T=3, density=2.60e-3,
+                gnn_X=dict(hidden_t=16, hidden_X=512, hidden_Y=64, num_gnn_layers=2, dropout=0.0),
+                gnn_E=dict(hidden_t=16, hidden_X=512, hidden_Y=64, hidden_E=128, num_gnn_layers=2, dropout=0.0))
+SMALL = dict(name="cora_shape", N=2708, F=1433, C=7, T=3, density=1.44e-3,
+             gnn_X=dict(hidden_t=32, hidden_X=512, hidden_Y=64, num_gnn_layers=2, dropout=0.0),
+             gnn_E=dict(hidden_t=32, hidden_X=512, hidden_Y=64, hidden_E=128, num_gnn_layers=2, dropout=0.0))
+
+FLOP_PER_PAIR = 2 * 128 * 128 + 2 * 128 * 2 + 128      # 33,408
+F32_MFMA_PEAK_TFLOPS = 157.3                            # MI355X_MICROARCH.md: dense f32 matrix peak
+
+
+def build_model(wl, dev):
+    """Reference-shaped random init (torch default init, manual_seed(0)); output biases shifted so the heads sit in
+    a trained model's sparse regime instead of p = 0.5 (documented in DESIGN.md; costs are input-density driven)."""
+    import graphmaker_amd as gm
+    rs = np.random.RandomState(0)
+    p1 = rs.uniform(0.002, 0.02, size=wl["F"]).astype(np.float32)
+    Xm = torch.from_numpy(np.stack([1 - p1, p1], 1).astype(np.float32)).to(dev)
+    Ym = torch.full((wl["C"],), 1.0 / wl["C"], dtype=torch.float32, device=dev)
+    d = np.float32(wl["density"])
+    Em = torch.tensor([1.0 - d, d], dtype=torch.float32, device=dev)
+    torch.manual_seed(0)
+    model = gm.ModelSync(T=wl["T"], X_marginal=Xm, Y_marginal=Ym, E_marginal=Em, gnn_X_config=wl["gnn_X"],
+                         gnn_E_config=wl["gnn_E"], num_nodes=wl["N"])
+    with torch.no_grad():
+        b = model.graph_encoder.pred_E.mlp_out[2].bias
+        b[0] += 3.0
+        b[1] -= 3.0
+        bx = model.graph_encoder.pred_X.mlp_out[2].bias
+        bx[0::2] += 2.0
+        bx[1::2] -= 2.0
+    return model.to(dev).eval()
+
+
+def cpu_baseline(wl, model, state, budget_rows=768, threads=None):
+    """The CPU oracle (oracle/gm_oracle.c, kind "port") on this host: both towers on all N nodes, the pair stage on
+    the first `budget_rows` rows of the pair matrix, extrapolated to the whole step by pair count."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as orc
+    if threads:
+        orc.set_threads(threads)
+    n, T = wl["N"], wl["T"]
+    x, oh, Y32, bits = state
+    sdX = {k: v.detach().cpu().numpy() for k, v in model.graph_encoder.pred_X.state_dict().items()}
+    sdE = {k: v.detach().cpu().numpy() for k, v in model.graph_encoder.pred_E.state_dict().items()}
+    towerX = orc.Tower.from_state_dict(sdX, is_mlp=False)
+    towerE = orc.Tower.from_state_dict(sdE, is_mlp=False, prefix="gnn_encoder.")
+    pair = orc.PairMLP(sdE["mlp_out.0.weight"], sdE["mlp_out.0.bias"], sdE["mlp_out.2.weight"], sdE["mlp_out.2.bias"])
+    bits_np = bits.cpu().numpy().view(np.uint32)
+    oh_np, y_np, x_np = oh.cpu().numpy(), Y32.cpu().numpy(), x.cpu().numpy()
+    tab_E, tab_X = model.step_tables(T)
+    t0 = time.perf_counter()
+    rp, ci = orc.csr_from_bitmap(bits_np, n)
+    h = towerE.forward(np.float32(1.0), oh_np, y_np, rp, ci)
+    t1 = time.perf_counter()
+    rows = min(budget_rows, n)
+    orc.pair_score_sample(n, h, pair, bits_np, tab_E, seed=0, step=T, row_begin=0, row_end=rows)
+    t2 = time.perf_counter()
+    logits = towerX.forward(np.float32(1.0), oh_np, y_np, rp, ci)
+    orc.attr_posterior_sample(logits, x_np, tab_X, seed=0, step=T)
+    t3 = time.perf_counter()
+    P = n * (n - 1) // 2
+    p_sample = sum(n - 1 - i for i in range(rows))
+    t_pair_full = (t2 - t1) * P / p_sample
+    step_s = (t1 - t0) + t_pair_full + (t3 - t2)
+    return {"value": 1.0 / step_s, "unit": "steps/s", "cores": orc.get_threads(), "kind": "port",
+            "pair_scores_per_sec": p_sample / (t2 - t1),
+            "sample": f"edge+node towers and attribute draw on all {n} nodes ({t1 - t0 + t3 - t2:.1f} s); pair stage on rows "
+                      f"[0,{rows}) = {p_sample} of {P} pairs ({t2 - t1:.1f} s), extrapolated by pair count; encoder "
+                      "hoisted once per step (the reference re-runs it per 32768-pair batch)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="amazon_computer", choices=["amazon_computer", "cora_shape"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=768)
+    args = ap.parse_args()
+
+    wl = WORKLOAD if args.workload == "amazon_computer" else SMALL
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    plan = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+        from graphmaker_amd.parallel import ShardPlan
+        plan = ShardPlan.make(wl["N"], world, rank)
+
+    from graphmaker_amd import ops
+    model = build_model(wl, dev)
+    n, T = wl["N"], wl["T"]
+    Em = model.transition.E_marginal_host
+    Y32 = ops.prior_Y(n, model.Y_marginal, seed=0)
+    bits = ops.prior_E(n, float(Em[0]), float(Em[1]), dev, seed=0)
+    x, oh = ops.prior_X(n, model.X_marginal, seed=0)
+    nnz = int(ops.csr_from_bitmap(bits, n)[0][n].item())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_step(k):
+        return model.denoise_step(T, x, oh, Y32, bits, seed=1000 + k, plan=plan)
+
+    for k in range(args.warmup):
+        one_step(k)
+    model.enable_phase_timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        out = one_step(args.warmup + k)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    phases = {k: float(np.mean(v)) for k, v in model.phase_times_ms().items()}
+    model.enable_phase_timing(False)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    P = n * (n - 1) // 2
+    ms_per_step = elapsed / args.steps * 1e3
+    pair_ms = phases.get("pair", float("nan"))                  # this rank's share of the pair matrix
+    pairs_here = P if plan is None else plan.pairs_of(rank)
+    achieved = FLOP_PER_PAIR * pairs_here / (pair_ms * 1e-3) / 1e12
+
+    if rank == 0:
+        res = {
+            "metric": "denoising steps/sec (amazon_computer Sync step); pair-scores/sec in pair_scores_per_sec",
+            "value": args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{wl['name']} GraphMaker-Sync reverse step t=T: N={n} F={wl['F']} C={wl['C']} "
+                                   f"hidden 512/64/{wl['gnn_E']['hidden_t']}/128, L=2; E_t = prior draw, nnz={nnz}; "
+                                   f"all P={P} unordered pairs (N^2 equivalent {2 * P + n})",
+                       "pairs_per_step": P, "parallelism": "single GPU" if world == 1 else
+                       f"{world} ranks: folded row chunks of the pair matrix, row-sharded tower output MLPs, "
+                       "3 all-gathers (h, E rows, X)"},
+            "pair_scores_per_sec": P / (elapsed / args.steps),
+            "pair_phase_scores_per_sec": pairs_here * (world if plan else 1) / (pair_ms * 1e-3),
+            "phases_ms_rank0": phases,
+            "roofline": {"kernel": "gm::k_pair_score_sample", "bound": "mfma", "achieved": achieved,
+                         "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
+                         "traffic": None, "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch_rank0": pairs_here,
+                         "launch_ms": pair_ms},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                res["cpu_baseline"] = cpu_baseline(wl, model, (x, oh, Y32, bits), budget_rows=args.cpu_rows,
+                                                   threads=int(os.environ.get("OMP_NUM_THREADS", "0")) or None)
+            except Exception as exc:  # the baseline must never take the GPU number down with it
+                res["cpu_baseline"] = {"value": None, "error": repr(exc)}
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -9,10 +9,11 @@ namespace gm {
 
 __global__ void k_attr_posterior_sample(int64_t n, int64_t F, const float* __restrict__ logits,
                                         const uint8_t* __restrict__ x_t, const float* __restrict__ tab,
-                                        const float* __restrict__ u, uint64_t seed, uint32_t step,
-                                        uint8_t* __restrict__ x_s, float* __restrict__ onehot, float* __restrict__ post) {
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n * F) return;
+                                        const float* __restrict__ u, uint64_t seed, uint32_t step, int64_t v_begin,
+                                        int64_t v_end, uint8_t* __restrict__ x_s, float* __restrict__ onehot,
+                                        float* __restrict__ post) {
+    const int64_t g = v_begin * F + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= v_end * F) return;
     const int64_t v = g / F, f = g % F;
     const float2 l = *reinterpret_cast<const float2*>(logits + 2 * g);
     float q0, q1, p0, p1;
@@ -94,14 +95,16 @@ using namespace gm;
 static inline unsigned blocks_for(int64_t total) { return (unsigned)((total + 255) / 256); }
 
 extern "C" int gm_attr_posterior_sample(int64_t n, int64_t F, const float* logits, const uint8_t* x_t, const float* tab,
-                                        const float* u, uint64_t seed, uint32_t step, uint8_t* x_s, float* onehot_out,
-                                        float* post_dbg, gm_stream_t stream) {
+                                        const float* u, uint64_t seed, uint32_t step, int64_t v_begin, int64_t v_end,
+                                        uint8_t* x_s, float* onehot_out, float* post_dbg, gm_stream_t stream) {
     GM_REQUIRE(n > 0 && F > 0 && logits && x_t && tab && x_s, "bad arguments");
+    GM_REQUIRE(0 <= v_begin && v_begin <= v_end && v_end <= n, "bad node range [%lld,%lld)", (long long)v_begin, (long long)v_end);
+    if (v_begin == v_end) return GM_OK;
     GM_REQUIRE(n * F < (1ll << 39), "n*F too large");
     GM_REQUIRE(aligned(logits, 8) && (!onehot_out || aligned(onehot_out, 8)) && (!post_dbg || aligned(post_dbg, 8)),
                "logits/onehot/post must be 8-byte aligned");
-    hipLaunchKernelGGL(k_attr_posterior_sample, dim3(blocks_for(n * F)), dim3(256), 0, as_stream(stream), n, F, logits, x_t, tab,
-                       u, seed, step, x_s, onehot_out, post_dbg);
+    hipLaunchKernelGGL(k_attr_posterior_sample, dim3(blocks_for((v_end - v_begin) * F)), dim3(256), 0, as_stream(stream), n, F,
+                       logits, x_t, tab, u, seed, step, v_begin, v_end, x_s, onehot_out, post_dbg);
     GM_LAUNCH_CHECK();
     return GM_OK;
 }

@@ -114,6 +114,15 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
         }
         __syncthreads();
 
+        // Waves w and w+4 share a SIMD and run the same program: in lockstep their VALU epilogues coincide and the
+        // matrix pipe idles.  Delaying the second half by ~16k cycles per tile (its partner has the pipe to itself
+        // meanwhile, and gets the time back at the tile's end) makes one wave's epilogue overlap the other's MFMAs.
+#ifndef GM_PAIR_NO_STAGGER
+        if (wv >= 4) {
+            __builtin_amdgcn_s_sleep(127);
+            __builtin_amdgcn_s_sleep(127);
+        }
+#endif
         // ---- each wave: 8 rows i, both 32-column halves of the tile per row
         for (int rr = 0; rr < TILE / 8; ++rr) {
             const int il = wv + 8 * rr;
@@ -159,7 +168,15 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
                 }
             }
 
-            // ---- epilogue: second layer, softmax, posterior, draw, bitmap word
+#ifdef GM_PAIR_NO_EPILOGUE   // exploration only: time the MFMA loop alone (results are garbage)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) asm volatile("" ::"v"(acc[s][mt]));
+            continue;
+#endif
+            // ---- epilogue: second layer (in-lane dot over this lane's 64 hidden units, both strips)
+            float part[2][2];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 float l0 = 0.0f, l1 = 0.0f;
@@ -180,36 +197,47 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
                             l1 = __builtin_fmaf(hid, w1v[r4], l1);
                         }
                     }
-                const float o0 = __shfl_xor(l0, 32), o1 = __shfl_xor(l1, 32);
-                const float s00 = half ? o0 : l0, s01 = half ? l0 : o0;   // (half-0 partial) + (half-1 partial)
-                const float s10 = half ? o1 : l1, s11 = half ? l1 : o1;
-                const float L0 = (s00 + s01) + b20;
-                const float L1 = (s10 + s11) + b21;
+                part[s][0] = l0;
+                part[s][1] = l1;
+            }
+            // Half-wave h finishes strip h: it keeps its own partial of that strip and receives the partner's
+            // (lane ^ 32) partial of the same strip, so softmax / posterior / draw run once per pair.
+            const float send0 = half ? part[0][0] : part[1][0];
+            const float send1 = half ? part[0][1] : part[1][1];
+            const float recv0 = __shfl_xor(send0, 32), recv1 = __shfl_xor(send1, 32);
+            const float own0 = half ? part[1][0] : part[0][0];
+            const float own1 = half ? part[1][1] : part[0][1];
+            // (hidden units with bit 2 clear) + (bit 2 set), then the bias: the oracle's order
+            const float L0 = ((half ? recv0 : own0) + (half ? own0 : recv0)) + b20;
+            const float L1 = ((half ? recv1 : own1) + (half ? own1 : recv1)) + b21;
 
-                const int64_t j = j0 + 32 * s + l31;
-                const int64_t wi = 2 * (int64_t)tj + s;
-                const bool valid = (j > i) && (j < a.n);
-                uint32_t etw = 0;
-                if (wi < a.wpr) etw = a.bits_t[i * a.wpr + wi];
-                const bool e = (etw >> l31) & 1u;
-                float q0, q1;
-                softmax2(L0, L1, q0, q1);
-                const float a0 = q0 * (e ? t0e1 : t0e0);
-                const float c0 = q1 * (e ? t2e1 : t2e0);
-                const float a1 = q0 * (e ? t1e1 : t1e0);
-                const float c1 = q1 * (e ? t3e1 : t3e0);
-                const float p0 = a0 + c0, p1 = a1 + c1;
-                const int64_t rank = i * (2 * a.n - i - 1) / 2 + (j - i - 1);
-                float u;
-                if (a.u) u = valid ? a.u[rank] : 1.0f;
-                else u = u_pair(a.seed, a.step, (uint32_t)i, (uint32_t)j);
-                const bool bit = valid && draw2(u, p0, p1);
-                const unsigned long long m = __ballot(bit);
-                if (lane == 0 && wi < a.wpr) a.out_upper[i * a.wpr + wi] = (uint32_t)m;
-                if (valid && half == 0) {
-                    if (a.logits_dbg) { a.logits_dbg[2 * rank] = L0; a.logits_dbg[2 * rank + 1] = L1; }
-                    if (a.post_dbg) { a.post_dbg[2 * rank] = p0; a.post_dbg[2 * rank + 1] = p1; }
-                }
+            const int64_t j = j0 + lane;                       // lanes 0-31: strip 0, lanes 32-63: strip 1
+            const int64_t wi = 2 * (int64_t)tj + half;
+            const bool valid = (j > i) && (j < a.n);
+            uint32_t etw = 0;
+            if (wi < a.wpr) etw = a.bits_t[i * a.wpr + wi];
+            const bool e = (etw >> l31) & 1u;
+            float q0, q1;
+            softmax2(L0, L1, q0, q1);
+            const float a0 = q0 * (e ? t0e1 : t0e0);
+            const float c0 = q1 * (e ? t2e1 : t2e0);
+            const float a1 = q0 * (e ? t1e1 : t1e0);
+            const float c1 = q1 * (e ? t3e1 : t3e0);
+            const float p0 = a0 + c0, p1 = a1 + c1;
+            const int64_t rank = i * (2 * a.n - i - 1) / 2 + (j - i - 1);
+            float u;
+            if (a.u) u = valid ? a.u[rank] : 1.0f;
+            else u = u_pair(a.seed, a.step, (uint32_t)i, (uint32_t)j);
+            const bool bit = valid && draw2(u, p0, p1);
+            const unsigned long long m = __ballot(bit);
+            if (lane == 0) {
+                const int64_t w0i = 2 * (int64_t)tj;
+                if (w0i < a.wpr) a.out_upper[i * a.wpr + w0i] = (uint32_t)m;
+                if (w0i + 1 < a.wpr) a.out_upper[i * a.wpr + w0i + 1] = (uint32_t)(m >> 32);
+            }
+            if (valid) {
+                if (a.logits_dbg) { a.logits_dbg[2 * rank] = L0; a.logits_dbg[2 * rank + 1] = L1; }
+                if (a.post_dbg) { a.post_dbg[2 * rank] = p0; a.post_dbg[2 * rank + 1] = p1; }
             }
         }
     }

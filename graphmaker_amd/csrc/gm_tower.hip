@@ -72,10 +72,13 @@ extern "C" int gm_tower_workspace_bytes(const gm_tower_dims* dims, int64_t n, si
 
 extern "C" int gm_tower_forward(const gm_tower_dims* d, const float* const* P, int64_t n, const float* t_float,
                                 const float* X_one_hot, const int32_t* Y, const int32_t* rowptr, const int32_t* colidx,
-                                float* out, float* hcat_out, void* workspace, size_t workspace_bytes, gm_stream_t stream) {
+                                float* out, float* hcat_out, int64_t out_row_begin, int64_t out_row_end, void* workspace,
+                                size_t workspace_bytes, gm_stream_t stream) {
     if (int rc = check_dims(d, n)) return rc;
     GM_REQUIRE(P && t_float && X_one_hot && Y && out && workspace, "null pointer");
     GM_REQUIRE(d->is_mlp || (rowptr && (colidx || true)), "GNN tower needs a CSR adjacency");
+    GM_REQUIRE(0 <= out_row_begin && out_row_begin <= out_row_end && out_row_end <= n, "bad output row range [%lld,%lld)",
+               (long long)out_row_begin, (long long)out_row_end);
     const TowerWs L = tower_layout(d, n);
     GM_REQUIRE(workspace_bytes >= L.total, "workspace too small: need %zu bytes, got %zu", L.total, workspace_bytes);
     GM_REQUIRE(aligned(workspace, 256), "workspace must be 256-byte aligned");
@@ -129,8 +132,12 @@ extern "C" int gm_tower_forward(const gm_tower_dims* d, const float* const* P, i
     }
     // mlp_out (:138-142,165-176)
     const float* const* O = P + 9 + 8 * nl;
-    GM_TRY(gm_linear(n, Hc, Hc, hcat, Hc, O[0], Hc, O[1], mid, Hc, 1, stream));
-    GM_TRY(gm_linear(n, d->out_size, Hc, mid, Hc, O[2], Hc, O[3], out, d->out_size, 0, stream));
+    const int64_t rb = out_row_begin, rows = out_row_end - out_row_begin;
+    if (rows > 0) {
+        GM_TRY(gm_linear(rows, Hc, Hc, hcat + rb * Hc, Hc, O[0], Hc, O[1], mid + rb * Hc, Hc, 1, stream));
+        GM_TRY(gm_linear(rows, d->out_size, Hc, mid + rb * Hc, Hc, O[2], Hc, O[3], out + rb * d->out_size, d->out_size, 0,
+                         stream));
+    }
     if (hcat_out) GM_HIP(hipMemcpyAsync(hcat_out, hcat, sizeof(float) * (size_t)(n * Hc), hipMemcpyDeviceToDevice, s));
     return GM_OK;
 }

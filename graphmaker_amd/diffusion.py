@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import ops, parallel
 from .gnn import GNN, GNNAsymm
 
 __all__ = ["ModelSync", "ModelAsync", "NoiseSchedule", "MarginalTransition"]
@@ -121,6 +121,37 @@ class BaseModel(nn.Module):
         self.E_marginal = E_marginal
         self._sample_calls = 0
         self._pair_ws = None
+        self._prof = None          # None, or dict phase -> [(start_event, end_event)] (bench.py / profiling)
+
+    class _Phase:
+        """Brackets a phase of the step with events on torch's current stream (the stream every library call is
+        enqueued on) when profiling is on; free otherwise."""
+
+        def __init__(self, model, name):
+            self.rec = model._prof
+            self.name = name
+
+        def __enter__(self):
+            if self.rec is not None:
+                self.e0 = torch.cuda.Event(enable_timing=True)
+                self.e0.record()
+
+        def __exit__(self, *exc):
+            if self.rec is not None:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                self.rec.setdefault(self.name, []).append((self.e0, e1))
+            return False
+
+    def phase(self, name):
+        return BaseModel._Phase(self, name)
+
+    def enable_phase_timing(self, on=True):
+        self._prof = {} if on else None
+
+    def phase_times_ms(self):
+        """{phase: [ms per occurrence]}; call after torch.cuda.synchronize()."""
+        return {k: [a.elapsed_time(b) for a, b in v] for k, v in (self._prof or {}).items()}
 
     # ---- reference helper API
     def get_adj(self, E_t):
@@ -150,18 +181,60 @@ class BaseModel(nn.Module):
                                f"cuda first (got {dev}).  There is no CPU path.")
         return dev
 
-    def _structure_step(self, pred_E, t_float, X_one_hot, Y32, bits_t, tab_E, seed, step, u=None, rows=None):
-        """get_E_t (model/diffusion.py:428-472): returns (A_t, upper bitmap of E_s)."""
+    def _structure_step(self, pred_E, t_float, X_one_hot, Y32, bits_t, tab_E, seed, step, u=None, plan=None, group=None):
+        """get_E_t (model/diffusion.py:428-472): returns (A_t, symmetric bitmap of E_s).
+        plan: parallel.ShardPlan for the one-process-per-GPU decomposition (None = single GPU)."""
         n = self.num_nodes
-        A_t = ops.adjacency_from_bitmap(bits_t, n)
-        h = pred_E.gnn_encoder(t_float, X_one_hot, Y32, A_t)
+        with self.phase("csr"):
+            A_t = ops.adjacency_from_bitmap(bits_t, n)
+        enc = pred_E.gnn_encoder
+        with self.phase("tower_E"):
+            if plan is None:
+                h = enc(t_float, X_one_hot, Y32, A_t)
+            else:
+                h_pad = torch.empty((plan.world * plan.node_rows, enc._dims.out_size), dtype=torch.float32,
+                                    device=X_one_hot.device)
+                enc._run(t_float, X_one_hot, Y32, A_t, rows=plan.node_range(), out=h_pad[:n])
+        if plan is not None:
+            with self.phase("allgather_h"):
+                h = parallel.all_gather_node_rows(plan, h_pad, group)[:n]
         if self._pair_ws is None or self._pair_ws.device != h.device:
             self._pair_ws = torch.empty(256, dtype=torch.uint8, device=h.device)
-        r0, r1 = rows if rows is not None else (0, n)
         W1, b1, W2, b2 = pred_E.pair_params()
-        upper = ops.pair_score_sample(h, W1, b1, W2, b2, bits_t, tab_E, seed=seed, step=step, u=u, row_begin=r0,
-                                      row_end=r1, workspace=self._pair_ws)
-        return A_t, upper
+        ranges = [(0, n)] if plan is None else plan.pair_chunks()
+        upper = torch.zeros((n, bits_t.shape[1]), dtype=torch.int32, device=h.device)
+        with self.phase("pair"):
+            for r0, r1 in ranges:
+                if r1 > r0:
+                    ops.pair_score_sample(h, W1, b1, W2, b2, bits_t, tab_E, seed=seed, step=step, u=u, row_begin=r0,
+                                          row_end=r1, out_upper=upper, workspace=self._pair_ws)
+        if plan is not None:
+            with self.phase("allgather_E"):
+                parallel.gather_upper_rows(plan, upper, group)
+        with self.phase("symmetrize"):
+            bits_s = ops.symmetrize_upper(upper, n)
+        return A_t, bits_s
+
+    def _attribute_draw(self, logits_fn, x, tab_X, seed, step, u=None, plan=None, group=None):
+        """softmax + posterior + sample_X (model/diffusion.py:879-895) on this rank's node rows, then replicate.
+        logits_fn(rows) -> (n, 2F) logits valid on `rows`."""
+        n = self.num_nodes
+        dev = x.device
+        rows = None if plan is None else plan.node_range()
+        with self.phase("tower_X"):
+            logits = logits_fn(rows)
+        tabX_dev = torch.from_numpy(tab_X).to(dev)
+        if plan is None:
+            with self.phase("attr"):
+                return ops.attr_posterior_sample(logits, x, tabX_dev, seed=seed, step=step, u=u)
+        x_pad = torch.empty((plan.world * plan.node_rows, x.shape[1]), dtype=torch.uint8, device=dev)
+        with self.phase("attr"):
+            ops.attr_posterior_sample(logits, x, tabX_dev, seed=seed, step=step, u=u, rows=rows, x_s=x_pad[:n],
+                                      want_onehot=False)
+        with self.phase("allgather_X"):
+            x_s = parallel.all_gather_node_rows(plan, x_pad, group)[:n]
+        with self.phase("attr"):
+            return x_s, ops.onehot_from_x(x_s)
 
     def _finish(self, x_onehot, Y32, bits, dense):
         n, Fa = self.num_nodes, self.num_attrs_X
@@ -189,24 +262,25 @@ class ModelSync(BaseModel):
         return self.transition.table_E(a_t, ab_s, ab_t), self.transition.table_X(a_t, ab_s, ab_t)
 
     @torch.no_grad()
-    def denoise_step(self, t, x, x_onehot, Y32, bits_t, seed, uniforms=None):
+    def denoise_step(self, t, x, x_onehot, Y32, bits_t, seed, uniforms=None, plan=None, group=None):
         """One reverse step t -> t-1 (the body of the loop at model/diffusion.py:847-896).
         State: x (N,F) uint8, x_onehot (N,2F) float, Y32 (N,) int32, bits_t symmetric bitmap.
         Returns (x_s, x_onehot_s, bits_s)."""
         dev = x.device
+        n = self.num_nodes
         tab_E, tab_X = self.step_tables(t)
         t_float = torch.tensor([t / self.T], dtype=torch.float32).to(dev)      # :860
         uE = uniforms.get(("E", t)) if uniforms else None
         uX = uniforms.get(("X", t)) if uniforms else None
-        A_t, upper = self._structure_step(self.graph_encoder.pred_E, t_float, x_onehot, Y32, bits_t, tab_E, seed, t, u=uE)
-        bits_s = ops.symmetrize_upper(upper, self.num_nodes)
-        logits = self.graph_encoder.pred_X(t_float, x_onehot, Y32, A_t)         # A_t of E_t, not E_s (:875-878)
-        tabX_dev = torch.from_numpy(tab_X).to(dev)
-        x_s, oh_s = ops.attr_posterior_sample(logits.reshape(self.num_nodes, -1), x, tabX_dev, seed=seed, step=t, u=uX)
+        A_t, bits_s = self._structure_step(self.graph_encoder.pred_E, t_float, x_onehot, Y32, bits_t, tab_E, seed, t,
+                                           u=uE, plan=plan, group=group)
+        pred_X = self.graph_encoder.pred_X                                      # A_t of E_t, not E_s (:875-878)
+        x_s, oh_s = self._attribute_draw(lambda rows: pred_X._run(t_float, x_onehot, Y32, A_t, rows=rows), x, tab_X,
+                                         seed, t, u=uX, plan=plan, group=group)
         return x_s, oh_s, bits_s
 
     @torch.no_grad()
-    def sample(self, batch_size=32768, num_workers=4, *, seed=None, uniforms=None, dense=True):
+    def sample(self, batch_size=32768, num_workers=4, *, seed=None, uniforms=None, dense=True, plan=None, group=None):
         """model/diffusion.py:797-905.  batch_size / num_workers are accepted and ignored (no pair batches exist).
         seed: Philox key (default derived from torch.initial_seed() and the call count).
         uniforms: optional dict of device float32 arrays with host-supplied draws, keys "Y", "E_prior", ("X", t)
@@ -221,7 +295,8 @@ class ModelSync(BaseModel):
         bits = ops.prior_E(n, float(Em[0]), float(Em[1]), dev, seed=seed, u=uni.get("E_prior"))        # :836-839
         x, x_onehot = ops.prior_X(n, self.X_marginal.float().contiguous(), seed=seed, u=uni.get(("X", 0)))  # :842-844
         for s in reversed(range(0, self.T)):                                                            # :847
-            x, x_onehot, bits = self.denoise_step(s + 1, x, x_onehot, Y32, bits, seed, uniforms=uni)
+            x, x_onehot, bits = self.denoise_step(s + 1, x, x_onehot, Y32, bits, seed, uniforms=uni, plan=plan,
+                                                  group=group)
         return self._finish(x_onehot, Y32, bits, dense)
 
 
@@ -250,27 +325,27 @@ class ModelAsync(BaseModel):
         return self.transition.table_E(ns.alphas_host[t], ns.alpha_bars_host[t - 1], ns.alpha_bars_host[t])
 
     @torch.no_grad()
-    def attribute_step(self, t, x, x_onehot, Y32, seed, uniforms=None):
+    def attribute_step(self, t, x, x_onehot, Y32, seed, uniforms=None, plan=None, group=None):
         """Body of the loop at model/diffusion.py:1330-1358."""
         dev = x.device
         t_float = torch.tensor([t / self.T_X], dtype=torch.float32).to(dev)
-        logits = self.graph_encoder.pred_X(t_float, x_onehot, Y32)
-        tabX_dev = torch.from_numpy(self.table_X(t)).to(dev)
+        pred_X = self.graph_encoder.pred_X
         uX = uniforms.get(("X", t)) if uniforms else None
-        return ops.attr_posterior_sample(logits.reshape(self.num_nodes, -1), x, tabX_dev, seed=seed, step=t, u=uX)
+        return self._attribute_draw(lambda rows: pred_X._run(t_float, x_onehot, Y32, None, rows=rows), x, self.table_X(t),
+                                    seed, t, u=uX, plan=plan, group=group)
 
     @torch.no_grad()
-    def structure_step(self, t, x_onehot, Y32, bits_t, seed, uniforms=None):
+    def structure_step(self, t, x_onehot, Y32, bits_t, seed, uniforms=None, plan=None, group=None):
         """Body of the loop at model/diffusion.py:1379-1401."""
         dev = x_onehot.device
         t_float = torch.tensor([t / self.T_E], dtype=torch.float32).to(dev)
         uE = uniforms.get(("E", t)) if uniforms else None
-        _, upper = self._structure_step(self.graph_encoder.pred_E, t_float, x_onehot, Y32, bits_t, self.table_E(t), seed,
-                                        t, u=uE)
-        return ops.symmetrize_upper(upper, self.num_nodes)
+        _, bits_s = self._structure_step(self.graph_encoder.pred_E, t_float, x_onehot, Y32, bits_t, self.table_E(t), seed,
+                                         t, u=uE, plan=plan, group=group)
+        return bits_s
 
     @torch.no_grad()
-    def sample(self, batch_size=32768, num_workers=4, *, seed=None, uniforms=None, dense=True):
+    def sample(self, batch_size=32768, num_workers=4, *, seed=None, uniforms=None, dense=True, plan=None, group=None):
         """model/diffusion.py:1295-1410: attributes first (T_X steps, no graph), then structure (T_E steps)."""
         dev = self._device()
         n = self.num_nodes
@@ -280,8 +355,8 @@ class ModelAsync(BaseModel):
         Y32 = ops.prior_Y(n, self.Y_marginal.float().contiguous(), seed=seed, u=uni.get("Y"))          # :1319-1321
         x, x_onehot = ops.prior_X(n, self.X_marginal.float().contiguous(), seed=seed, u=uni.get(("X", 0)))  # :1325-1327
         for s_X in reversed(range(0, self.T_X)):                                                        # :1330
-            x, x_onehot = self.attribute_step(s_X + 1, x, x_onehot, Y32, seed, uniforms=uni)
+            x, x_onehot = self.attribute_step(s_X + 1, x, x_onehot, Y32, seed, uniforms=uni, plan=plan, group=group)
         bits = ops.prior_E(n, float(Em[0]), float(Em[1]), dev, seed=seed, u=uni.get("E_prior"))        # :1362-1365
         for s_E in reversed(range(0, self.T_E)):                                                        # :1379
-            bits = self.structure_step(s_E + 1, x_onehot, Y32, bits, seed, uniforms=uni)
+            bits = self.structure_step(s_E + 1, x_onehot, Y32, bits, seed, uniforms=uni, plan=plan, group=group)
         return self._finish(x_onehot, Y32, bits, dense)

@@ -80,7 +80,7 @@ class _TowerBase(nn.Module):
             self._ws = torch.empty(need, dtype=torch.uint8, device=device)
         return self._ws
 
-    def _run(self, t_float, X_t_one_hot, Y_real, A_t, want_hcat=False):
+    def _run(self, t_float, X_t_one_hot, Y_real, A_t, want_hcat=False, rows=None, out=None):
         if self.training and any(m.p > 0 for m in self.modules() if isinstance(m, nn.Dropout)):
             raise NotImplementedError("graphmaker_amd towers run in eval mode only (dropout is not implemented)")
         n = X_t_one_hot.shape[0]
@@ -88,7 +88,7 @@ class _TowerBase(nn.Module):
         Y32 = Y_real if Y_real.dtype == torch.int32 else Y_real.to(torch.int32)
         t = t_float.reshape(1).to(torch.float32)
         return ops.tower_forward(self._dims, self._param_ptrs(), n, t, X, Y32.contiguous(), A_t,
-                                 self._workspace(n, X.device), want_hcat=want_hcat)
+                                 self._workspace(n, X.device), want_hcat=want_hcat, rows=rows, out=out)
 
 
 class GNNTower(_TowerBase):

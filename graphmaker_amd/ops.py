@@ -118,7 +118,7 @@ def tower_workspace_bytes(dims, n):
     return nbytes.value
 
 
-def tower_forward(dims, param_ptrs, n, t_float, X_one_hot, Y32, adj, workspace, out=None, want_hcat=False):
+def tower_forward(dims, param_ptrs, n, t_float, X_one_hot, Y32, adj, workspace, out=None, want_hcat=False, rows=None):
     require(t_float, torch.float32, "t_float")
     require(X_one_hot, torch.float32, "X_t_one_hot")
     require(Y32, torch.int32, "Y")
@@ -131,7 +131,8 @@ def tower_forward(dims, param_ptrs, n, t_float, X_one_hot, Y32, adj, workspace, 
     rowptr = adj.rowptr if adj is not None else None
     colidx = adj.colidx if adj is not None else None
     L.call("gm_tower_forward", C.byref(dims), param_ptrs, I64(n), ptr(t_float), ptr(X_one_hot), ptr(Y32), ptr(rowptr),
-           ptr(colidx), ptr(out), ptr(hcat), ptr(workspace), C.c_size_t(workspace.numel()), stream_ptr())
+           ptr(colidx), ptr(out), ptr(hcat), I64(rows[0] if rows else 0), I64(rows[1] if rows else n), ptr(workspace),
+           C.c_size_t(workspace.numel()), stream_ptr())
     return (out, hcat) if want_hcat else out
 
 
@@ -175,17 +176,18 @@ def pair_score_sample(h, W1, b1, W2, b2, bits_t, tab, *, seed=0, step=0, u=None,
 
 
 # ------------------------------------------------------------------ attributes
-def attr_posterior_sample(logits, x_t, tab, *, seed=0, step=0, u=None, want_onehot=True, want_debug=False):
+def attr_posterior_sample(logits, x_t, tab, *, seed=0, step=0, u=None, want_onehot=True, want_debug=False, rows=None,
+                          x_s=None):
     require(logits, torch.float32, "logits")
     require(x_t, torch.uint8, "x_t")
     require(tab, torch.float32, "tab")
     n, F = x_t.shape
     dev = x_t.device
-    x_s = torch.empty_like(x_t)
+    x_s = torch.empty_like(x_t) if x_s is None else x_s
     oh = torch.empty((n, 2 * F), dtype=torch.float32, device=dev) if want_onehot else None
     po = torch.empty((n, F, 2), dtype=torch.float32, device=dev) if want_debug else None
     L.call("gm_attr_posterior_sample", I64(n), I64(F), ptr(logits), ptr(x_t), ptr(tab), ptr(u), U64(seed), U32(step),
-           ptr(x_s), ptr(oh), ptr(po), stream_ptr())
+           I64(rows[0] if rows else 0), I64(rows[1] if rows else n), ptr(x_s), ptr(oh), ptr(po), stream_ptr())
     res = (x_s, oh)
     return res + (po,) if want_debug else res
 

@@ -88,11 +88,15 @@ int gm_layernorm(int64_t M, int64_t N, float* X, int64_t ldx, const float* gamma
  *   per layer: update_X.0.{weight,bias}, update_X.2.{weight,bias}, update_Y.0.{weight,bias}, update_Y.2.{weight,bias},
  *   mlp_out.{0,2}.{weight,bias}                                   (9 + 8*num_layers + 4 pointers)
  * t_float: device pointer to one float (the reference passes a (1,) tensor, model/diffusion.py:860).
- * out: (n, out_size) row-major.  hcat_out: optional (n, hidden_cat) copy of the concatenated hidden state. */
+ * out: (n, out_size) row-major.  hcat_out: optional (n, hidden_cat) copy of the concatenated hidden state.
+ * [out_row_begin, out_row_end): rows of `out` to produce.  The graph part of the tower always runs on all n nodes
+ * (message passing needs every row); the row-independent output MLP (model/gnn.py:138-142), most of the FLOPs,
+ * runs only on this range, which is how one tower is sharded over GPUs (pass 0, n for everything). */
 int gm_tower_workspace_bytes(const gm_tower_dims* dims, int64_t n, size_t* bytes);
 int gm_tower_forward(const gm_tower_dims* dims, const float* const* params, int64_t n, const float* t_float,
                      const float* X_one_hot, const int32_t* Y, const int32_t* rowptr, const int32_t* colidx,
-                     float* out, float* hcat_out, void* workspace, size_t workspace_bytes, gm_stream_t stream);
+                     float* out, float* hcat_out, int64_t out_row_begin, int64_t out_row_end, void* workspace,
+                     size_t workspace_bytes, gm_stream_t stream);
 
 /* z[b] = h[src[b]] * h[dst[b]] for an explicit pair list: LinkPredictor.forward on a caller-chosen batch
  * (model/gnn.py:246); followed by two gm_linear calls it gives the (B,2) logits of model/gnn.py:248. */
@@ -112,10 +116,11 @@ int gm_pair_score_sample(int64_t n, int64_t hE, const float* h, const float* W1,
                          gm_stream_t stream);
 
 /* ---- attribute posterior + draw: model/diffusion.py:879-895 + sample_X :214-237 ----
- * logits (n,F,2); tab device (F,8) per-attribute posterior tables; x_s (n,F) uint8; onehot_out optional (n,2F). */
+ * logits (n,F,2); tab device (F,8) per-attribute posterior tables; x_s (n,F) uint8; onehot_out optional (n,2F).
+ * Only nodes [v_begin, v_end) are processed (all pointers address the full arrays): the per-GPU shard. */
 int gm_attr_posterior_sample(int64_t n, int64_t F, const float* logits, const uint8_t* x_t, const float* tab,
-                             const float* u, uint64_t seed, uint32_t step, uint8_t* x_s, float* onehot_out,
-                             float* post_dbg, gm_stream_t stream);
+                             const float* u, uint64_t seed, uint32_t step, int64_t v_begin, int64_t v_end,
+                             uint8_t* x_s, float* onehot_out, float* post_dbg, gm_stream_t stream);
 int gm_onehot_from_x(int64_t n, int64_t F, const uint8_t* x, float* onehot, gm_stream_t stream);
 int gm_x_from_onehot(int64_t n, int64_t F, const float* onehot, uint8_t* x, gm_stream_t stream);
 

@@ -325,6 +325,7 @@ void gmo_spmm_mean(int64_t n, const int32_t* rowptr, const int32_t* colidx, cons
         float inv = 1.0f / (float)(e - b);
         for (int32_t p = b; p < e; ++p) {
             const float* hrow = H + (int64_t)colidx[p] * ldh;
+#pragma omp simd
             for (int64_t c = 0; c < d; ++c) o[c] = fmaf(hrow[c], inv, o[c]);
         }
     }
@@ -353,6 +354,7 @@ void gmo_linear(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, co
                 for (int64_t r = 0; r < mr; ++r) {
                     float a = A[(m0 + r) * lda + k];
                     float* ar = acc[r];
+#pragma omp simd
                     for (int64_t c = 0; c < nb; ++c) ar[c] = fmaf(a, wrow[c], ar[c]);
                 }
             }
@@ -509,35 +511,62 @@ void gmo_pair_score_sample(int64_t n, int64_t hE, const float* h, const float* W
         uint32_t* orow = out_upper + i * wpr;
         for (int64_t w = 0; w < wpr; ++w) orow[w] = 0u;
         const float* hi = h + i * hE;
-        float z[1024], hid[1024];
-        for (int64_t j = i + 1; j < n; ++j) {
-            const float* hj = h + j * hE;
-            for (int64_t k = 0; k < hE; ++k) z[k] = hi[k] * hj[k];
-            for (int64_t o = 0; o < hE; ++o) hid[o] = b1[o];
-            for (int64_t k = 0; k < hE; ++k) {
-                float zk = z[k];
-                const float* wr = W1t + k * hE;
-                for (int64_t o = 0; o < hE; ++o) hid[o] = fmaf(zk, wr[o], hid[o]);
+        enum { JB = 4, OB = 16 };
+        float z[JB][1024], hid[JB][1024];
+        for (int64_t jb0 = i + 1; jb0 < n; jb0 += JB) {
+            const int nj = (int)(n - jb0 < JB ? n - jb0 : JB);
+            for (int b = 0; b < JB; ++b) {
+                const float* hj = h + (b < nj ? jb0 + b : jb0) * hE;
+                for (int64_t k = 0; k < hE; ++k) z[b][k] = hi[k] * hj[k];
             }
-            float logit[2];
-            for (int c = 0; c < 2; ++c) {
-                float s[2] = {0.0f, 0.0f};
-                for (int64_t o = 0; o < hE; ++o) {
-                    float r = hid[o] > 0.0f ? hid[o] : 0.0f;
-                    int hsel = (int)((o >> 2) & 1);
-                    s[hsel] = fmaf(r, W2[c * hE + o], s[hsel]);
+            /* register-blocked: 4 pairs x 16 hidden units stay in registers across the k loop; every (pair, o)
+             * still sees hid = b1[o], then fmaf over ascending k */
+            for (int64_t o0 = 0; o0 < hE; o0 += OB) {
+                if (o0 + OB <= hE) {
+                    float acc[JB][OB];
+                    for (int b = 0; b < JB; ++b)
+                        for (int oo = 0; oo < OB; ++oo) acc[b][oo] = b1[o0 + oo];
+                    for (int64_t k = 0; k < hE; ++k) {
+                        const float* wr = W1t + k * hE + o0;
+                        for (int b = 0; b < JB; ++b) {
+                            const float zk = z[b][k];
+#pragma omp simd
+                            for (int oo = 0; oo < OB; ++oo) acc[b][oo] = fmaf(zk, wr[oo], acc[b][oo]);
+                        }
+                    }
+                    for (int b = 0; b < JB; ++b)
+                        for (int oo = 0; oo < OB; ++oo) hid[b][o0 + oo] = acc[b][oo];
+                } else {
+                    for (int b = 0; b < JB; ++b)
+                        for (int64_t o = o0; o < hE; ++o) {
+                            float acc = b1[o];
+                            for (int64_t k = 0; k < hE; ++k) acc = fmaf(z[b][k], W1t[k * hE + o], acc);
+                            hid[b][o] = acc;
+                        }
                 }
-                logit[c] = (s[0] + s[1]) + b2[c];
             }
-            float q0, q1, p0, p1;
-            gmo_softmax2(logit[0], logit[1], &q0, &q1);                      /* diffusion.py:457 */
-            int e_t = (int)((bits_t[i * wpr + (j >> 5)] >> (j & 31)) & 1u);  /* diffusion.py:460-462 */
-            gmo_posterior_apply(tab, e_t, q0, q1, &p0, &p1);                 /* diffusion.py:463-464 */
-            int64_t r = pair_rank(n, i, j);
-            float u = u_or_null ? u_or_null[r] : u_E(seed, step, i, j);
-            if (draw2(u, p0, p1)) orow[j >> 5] |= 1u << (j & 31);            /* diffusion.py:421 */
-            if (logits_dbg) { logits_dbg[2 * r] = logit[0]; logits_dbg[2 * r + 1] = logit[1]; }
-            if (post_dbg) { post_dbg[2 * r] = p0; post_dbg[2 * r + 1] = p1; }
+            for (int b = 0; b < nj; ++b) {
+                const int64_t j = jb0 + b;
+                float logit[2];
+                for (int c = 0; c < 2; ++c) {
+                    float s[2] = {0.0f, 0.0f};
+                    for (int64_t o = 0; o < hE; ++o) {
+                        float r = hid[b][o] > 0.0f ? hid[b][o] : 0.0f;
+                        int hsel = (int)((o >> 2) & 1);
+                        s[hsel] = fmaf(r, W2[c * hE + o], s[hsel]);
+                    }
+                    logit[c] = (s[0] + s[1]) + b2[c];
+                }
+                float q0, q1, p0, p1;
+                gmo_softmax2(logit[0], logit[1], &q0, &q1);                      /* diffusion.py:457 */
+                int e_t = (int)((bits_t[i * wpr + (j >> 5)] >> (j & 31)) & 1u);  /* diffusion.py:460-462 */
+                gmo_posterior_apply(tab, e_t, q0, q1, &p0, &p1);                 /* diffusion.py:463-464 */
+                int64_t r = pair_rank(n, i, j);
+                float u = u_or_null ? u_or_null[r] : u_E(seed, step, i, j);
+                if (draw2(u, p0, p1)) orow[j >> 5] |= 1u << (j & 31);            /* diffusion.py:421 */
+                if (logits_dbg) { logits_dbg[2 * r] = logit[0]; logits_dbg[2 * r + 1] = logit[1]; }
+                if (post_dbg) { post_dbg[2 * r] = p0; post_dbg[2 * r + 1] = p1; }
+            }
         }
     }
     free(W1t);
