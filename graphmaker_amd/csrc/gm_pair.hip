@@ -17,7 +17,12 @@
 // bit-identical to oracle gmo_pair_logits.
 //
 // Tiling: persistent workgroups (512 threads = 8 waves, 2 per SIMD) pull 64x64 tiles of the upper triangle from an
-// atomic counter.  W1 (64 KB) stays in LDS for the whole kernel; per tile the 64 h_i rows and 64 h_j rows are staged
+// atomic counter.  The two waves of a SIMD (w and w+4) take turns on the matrix pipe: one runs the 512 MFMAs of its
+// next row (both 32-column strips) while the other runs the VALU epilogue of the row it has just finished; the turn
+// passes through a flag in LDS.  (Left to the hardware, the older wave wins every MFMA arbitration, the younger one
+// starves and later runs alone with its epilogues exposed.)  LDS fragments for k-block q+1 are read while the MFMAs
+// of block q run.  Measured anatomy of one 512-MFMA row-unit (ideal 32,768 cycles): 33.9k with operands in
+// registers, +1.9k for the 176 ds_read_b128 that feed it, +~1k hand-over/epilogue interference (profiles/).  W1 (64 KB) stays in LDS for the whole kernel; per tile the 64 h_i rows and 64 h_j rows are staged
 // (64 KB), i.e. 16 B of HBM/L2 traffic per pair against 33,408 FLOP: MFMA-bound (f32 matrix peak 157 TFLOP/s).
 #include "gm_common.h"
 
@@ -60,18 +65,55 @@ __device__ __forceinline__ void put_split(float* row, int c4, float4 v) {
     *reinterpret_cast<float2*>(row + 64 + 2 * c4) = make_float2(v.y, v.w);
 }
 
+struct Frag {
+    float4 w[4];
+    float4 hi, ha, hb;
+};
+
+__device__ __forceinline__ void load_frag(Frag& f, const float* wrow, const float* hirow, const float* hjrow, int q) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) f.w[mt] = *reinterpret_cast<const float4*>(wrow + mt * 32 * LDR + 4 * q);
+    f.hi = *reinterpret_cast<const float4*>(hirow + 4 * q);
+    f.ha = *reinterpret_cast<const float4*>(hjrow + 4 * q);
+    f.hb = *reinterpret_cast<const float4*>(hjrow + 32 * LDR + 4 * q);
+}
+
+// 4 k-steps (k = 8q .. 8q+7) on both strips: 32 MFMAs
+__device__ __forceinline__ void mma_frag(floatx16 (&acc)[2][4], const Frag& f) {
+    const float hiv[4] = {f.hi.x, f.hi.y, f.hi.z, f.hi.w};
+    const float hav[4] = {f.ha.x, f.ha.y, f.ha.z, f.ha.w};
+    const float hbv[4] = {f.hb.x, f.hb.y, f.hb.z, f.hb.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float z0 = hiv[e] * hav[e];
+        const float z1 = hiv[e] * hbv[e];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const float wv_ = e == 0 ? f.w[mt].x : e == 1 ? f.w[mt].y : e == 2 ? f.w[mt].z : f.w[mt].w;
+            acc[0][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv_, z0, acc[0][mt], 0, 0, 0);
+            acc[1][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv_, z1, acc[1][mt], 0, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ float relu_bits(float x) {   // max(x, 0) for non-NaN x, one integer max
+    return __int_as_float(max(__float_as_int(x), 0));
+}
+
 __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const PairArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[(HE + 2 * TILE) * LDR + HE + 2 * HE + 4];
+    __shared__ __attribute__((aligned(16))) float lds[(HE + 2 * TILE) * LDR + HE + 2 * HE + 16];
     float* W1s = lds;
     float* hIs = W1s + HE * LDR;
     float* hJs = hIs + TILE * LDR;
     float* b1s = hJs + TILE * LDR;
     float* W2s = b1s + HE;
     int* tile_s = reinterpret_cast<int*>(W2s + 2 * HE);
+    int* turn_s = tile_s + 4;                      // turn_s[w]: MFMA row-units wave w has issued so far (hand-off flags)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wv >> 2;                       // waves w and w+4 share a SIMD: group 0 / group 1
     const int l31 = lane & 31, half = lane >> 5;
 
     // ---- stage the pair MLP once per workgroup
@@ -82,16 +124,22 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
     if (tid < HE) b1s[tid] = a.b1[tid];
     if (tid < 2 * HE) W2s[tid] = a.W2[tid];
     const float b20 = a.b2[0], b21 = a.b2[1];
-    const float t0e0 = a.tab[0], t0e1 = a.tab[1], t1e0 = a.tab[2], t1e1 = a.tab[3];
-    const float t2e0 = a.tab[4], t2e1 = a.tab[5], t3e0 = a.tab[6], t3e1 = a.tab[7];
     const int64_t width = (int64_t)a.ntj - a.tjb;
 
-    for (;;) {
-        __syncthreads();  // everyone is done with the previous tile's LDS image (and with tile_s)
-        if (tid == 0) *tile_s = (int)atomicAdd(a.counter, 1u);
-        __syncthreads();
-        const int64_t t = *tile_s;
-        if (t >= a.ntiles) break;
+    if (tid == 0) *tile_s = (int)atomicAdd(a.counter, 1u);
+    if (tid < 8) turn_s[tid] = 0;
+    __syncthreads();
+    int64_t t = *tile_s;
+    bool staged = false;
+    int units_done = 0;                            // row-units this wave has multiplied (same count in every wave)
+    volatile int* my_turn = turn_s + wv;
+    volatile int* partner_turn = turn_s + (wv ^ 4);
+#ifdef GM_PAIR_STAMP   // diagnostic build: cycle sums of wave 0 / wave 4 of block 0 -> post_dbg (never in the product)
+    unsigned long long st_mma = 0, st_epi = 0, st_phase = 0, st_n = 0, st_init = 0;
+#define STAMP() __builtin_readcyclecounter()
+#endif
+
+    while (t < a.ntiles) {
         // decode t -> (ti, tj): largest ti with prefix(ti) <= t
         int lo = 0, hi = a.nti - 1;
         while (lo < hi) {
@@ -103,144 +151,197 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
         const int64_t i0 = a.row_begin + (int64_t)ti * TILE;
         const int64_t j0 = (int64_t)tj * TILE;
 
-        // ---- stage h rows of the tile: 2 x 64 rows x 32 float4
-        for (int q = tid; q < 2 * TILE * (HE / 4); q += PAIR_THREADS) {
-            const int which = q >> 11;             // 0: i rows, 1: j rows
-            const int r = (q >> 5) & (TILE - 1), c4 = q & 31;
-            const int64_t node = (which ? j0 : i0) + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (node < a.n) v = *reinterpret_cast<const float4*>(a.h + node * HE + 4 * c4);
-            put_split((which ? hJs : hIs) + r * LDR, c4, v);
+        if (!staged) {   // first tile of this workgroup; later tiles are staged at the hand-over below
+            for (int q = tid; q < 2 * TILE * (HE / 4); q += PAIR_THREADS) {
+                const int which = q >> 11;             // 0: i rows, 1: j rows
+                const int r = (q >> 5) & (TILE - 1), c4 = q & 31;
+                const int64_t node = (which ? j0 : i0) + r;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (node < a.n) v = *reinterpret_cast<const float4*>(a.h + node * HE + 4 * c4);
+                put_split((which ? hJs : hIs) + r * LDR, c4, v);
+            }
+            __syncthreads();
         }
-        __syncthreads();
 
-        // Waves w and w+4 share a SIMD and run the same program: in lockstep their VALU epilogues coincide and the
-        // matrix pipe idles.  Delaying the second half by ~16k cycles per tile (its partner has the pipe to itself
-        // meanwhile, and gets the time back at the tile's end) makes one wave's epilogue overlap the other's MFMAs.
-#ifndef GM_PAIR_NO_STAGGER
-        if (wv >= 4) {
-            __builtin_amdgcn_s_sleep(127);
-            __builtin_amdgcn_s_sleep(127);
-        }
+        floatx16 acc[2][4];
+        // 8 row-units per wave and tile.  The two waves of a SIMD (w, w+4) alternate on the matrix pipe: group 0 runs
+        // unit u, then group 1 runs unit u while group 0 does the VALU epilogue of its unit, and so on.  The turn is
+        // handed over through turn_s[] in LDS (no data passes between the waves, only the right to issue MFMAs).
+        for (int u = 0; u < TILE / 8; ++u) {
+#ifdef GM_PAIR_STAMP
+            const unsigned long long ph0 = STAMP();
 #endif
-        // ---- each wave: 8 rows i, both 32-column halves of the tile per row
-        for (int rr = 0; rr < TILE / 8; ++rr) {
-            const int il = wv + 8 * rr;
+            const int il = wv + 8 * u;
             const int64_t i = i0 + il;
-            if (i >= a.row_end || i >= a.n) continue;   // wave-uniform
-
-            floatx16 acc[2][4];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 bv = *reinterpret_cast<const float4*>(b1s + mt * 32 + 8 * g + 4 * half);
-                    acc[0][mt][4 * g + 0] = bv.x; acc[0][mt][4 * g + 1] = bv.y;
-                    acc[0][mt][4 * g + 2] = bv.z; acc[0][mt][4 * g + 3] = bv.w;
-                    acc[1][mt][4 * g + 0] = bv.x; acc[1][mt][4 * g + 1] = bv.y;
-                    acc[1][mt][4 * g + 2] = bv.z; acc[1][mt][4 * g + 3] = bv.w;
-                }
-
-            const float* wrow = W1s + l31 * LDR + 64 * half;
-            const float* hirow = hIs + il * LDR + 64 * half;
-            const float* hjrow = hJs + l31 * LDR + 64 * half;
-#pragma unroll 2
-            for (int q = 0; q < HE / 8; ++q) {
-                float4 w[4];
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) w[mt] = *reinterpret_cast<const float4*>(wrow + mt * 32 * LDR + 4 * q);
-                const float4 hi4 = *reinterpret_cast<const float4*>(hirow + 4 * q);
-                const float4 ha = *reinterpret_cast<const float4*>(hjrow + 4 * q);
-                const float4 hb = *reinterpret_cast<const float4*>(hjrow + 32 * LDR + 4 * q);
-                const float hiv[4] = {hi4.x, hi4.y, hi4.z, hi4.w};
-                const float hav[4] = {ha.x, ha.y, ha.z, ha.w};
-                const float hbv[4] = {hb.x, hb.y, hb.z, hb.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float z0 = hiv[e] * hav[e];
-                    const float z1 = hiv[e] * hbv[e];
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) {
-                        const float wv_ = e == 0 ? w[mt].x : e == 1 ? w[mt].y : e == 2 ? w[mt].z : w[mt].w;
-                        acc[0][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv_, z0, acc[0][mt], 0, 0, 0);
-                        acc[1][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv_, z1, acc[1][mt], 0, 0, 0);
-                    }
-                }
+            {   // wait for the partner: group 0 needs its partner's unit (units_done-1), group 1 its partner's unit units_done
+                const int need = units_done + grp;
+                // bounded: the order is a speed matter only, results never depend on it
+                for (int spin = 0; spin < (1 << 16) && *partner_turn < need; ++spin) __builtin_amdgcn_s_sleep(1);
             }
-
-#ifdef GM_PAIR_NO_EPILOGUE   // exploration only: time the MFMA loop alone (results are garbage)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) asm volatile("" ::"v"(acc[s][mt]));
-            continue;
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                if (i < a.row_end && i < a.n) {                  // wave-uniform
+#ifdef GM_PAIR_STAMP
+                    const unsigned long long m0 = STAMP();
 #endif
-            // ---- epilogue: second layer (in-lane dot over this lane's 64 hidden units, both strips)
-            float part[2][2];
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                float l0 = 0.0f, l1 = 0.0f;
+                    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int ob = mt * 32 + 8 * g + 4 * half;
-                        const float4 w0 = *reinterpret_cast<const float4*>(W2s + ob);
-                        const float4 w1 = *reinterpret_cast<const float4*>(W2s + HE + ob);
-                        const float w0v[4] = {w0.x, w0.y, w0.z, w0.w};
-                        const float w1v[4] = {w1.x, w1.y, w1.z, w1.w};
-#pragma unroll
-                        for (int r4 = 0; r4 < 4; ++r4) {
-                            float hid = acc[s][mt][4 * g + r4];
-                            hid = hid > 0.0f ? hid : 0.0f;
-                            l0 = __builtin_fmaf(hid, w0v[r4], l0);
-                            l1 = __builtin_fmaf(hid, w1v[r4], l1);
+                        for (int g = 0; g < 4; ++g) {
+                            const float4 bv = *reinterpret_cast<const float4*>(b1s + mt * 32 + 8 * g + 4 * half);
+                            acc[0][mt][4 * g + 0] = bv.x; acc[0][mt][4 * g + 1] = bv.y;
+                            acc[0][mt][4 * g + 2] = bv.z; acc[0][mt][4 * g + 3] = bv.w;
+                            acc[1][mt][4 * g + 0] = bv.x; acc[1][mt][4 * g + 1] = bv.y;
+                            acc[1][mt][4 * g + 2] = bv.z; acc[1][mt][4 * g + 3] = bv.w;
                         }
+                    const float* wrow = W1s + l31 * LDR + 64 * half;
+                    const float* hirow = hIs + il * LDR + 64 * half;
+                    const float* hjrow = hJs + l31 * LDR + 64 * half;
+                    // fragments for k-block q+1 are read from LDS while the 32 MFMAs of block q run
+                    Frag f0, f1;
+#ifdef GM_PAIR_STAMP
+                    const unsigned long long m1 = STAMP();
+                    st_init += m1 - m0;
+#endif
+                    load_frag(f0, wrow, hirow, hjrow, 0);
+#pragma unroll 1
+                    for (int q = 0; q < HE / 8; q += 2) {
+#ifdef GM_PAIR_NO_LDS   // exploration only
+                        if (q == 0)
+#endif
+                        load_frag(f1, wrow, hirow, hjrow, q + 1);
+                        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMAs it overlaps
+                        mma_frag(acc, f0);
+                        __builtin_amdgcn_sched_barrier(0);
+#ifndef GM_PAIR_NO_LDS
+                        load_frag(f0, wrow, hirow, hjrow, (q + 2) & (HE / 8 - 1));
+#endif
+                        __builtin_amdgcn_sched_barrier(0);
+                        mma_frag(acc, f1);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                part[s][0] = l0;
-                part[s][1] = l1;
+#ifdef GM_PAIR_STAMP
+                    asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[1][3]));
+                    st_mma += STAMP() - m1;
+                    st_n += 1;
+#endif
+                }
             }
-            // Half-wave h finishes strip h: it keeps its own partial of that strip and receives the partner's
-            // (lane ^ 32) partial of the same strip, so softmax / posterior / draw run once per pair.
-            const float send0 = half ? part[0][0] : part[1][0];
-            const float send1 = half ? part[0][1] : part[1][1];
-            const float recv0 = __shfl_xor(send0, 32), recv1 = __shfl_xor(send1, 32);
-            const float own0 = half ? part[1][0] : part[0][0];
-            const float own1 = half ? part[1][1] : part[0][1];
-            // (hidden units with bit 2 clear) + (bit 2 set), then the bias: the oracle's order
-            const float L0 = ((half ? recv0 : own0) + (half ? own0 : recv0)) + b20;
-            const float L1 = ((half ? recv1 : own1) + (half ? own1 : recv1)) + b21;
+            __builtin_amdgcn_sched_barrier(0);
+            ++units_done;
+            if (lane == 0) *my_turn = units_done;
+            __builtin_amdgcn_sched_barrier(0);
+            {
+#ifdef GM_PAIR_NO_EPILOGUE   // exploration only: results are garbage
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) asm volatile("" ::"v"(acc[s][mt]));
+                if (false) {
+#else
+                if (i < a.row_end && i < a.n) {
+#endif
+                    // ---- second layer: in-lane dot over this lane's 64 hidden units, both strips
+                    float part[2][2];
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        float l0 = 0.0f, l1 = 0.0f;
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const int ob = mt * 32 + 8 * g + 4 * half;
+                                const float4 w0 = *reinterpret_cast<const float4*>(W2s + ob);
+                                const float4 w1 = *reinterpret_cast<const float4*>(W2s + HE + ob);
+                                const float w0v[4] = {w0.x, w0.y, w0.z, w0.w};
+                                const float w1v[4] = {w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+                                for (int r4 = 0; r4 < 4; ++r4) {
+                                    const float hid = relu_bits(acc[s][mt][4 * g + r4]);
+                                    l0 = __builtin_fmaf(hid, w0v[r4], l0);
+                                    l1 = __builtin_fmaf(hid, w1v[r4], l1);
+                                }
+                            }
+                        part[s][0] = l0;
+                        part[s][1] = l1;
+                    }
+                    // Half-wave h finishes strip h: it keeps its own partial of that strip and receives the partner's
+                    // (lane ^ 32) partial of the same strip, so softmax / posterior / draw run once per pair.
+                    const float send0 = half ? part[0][0] : part[1][0];
+                    const float send1 = half ? part[0][1] : part[1][1];
+                    const float recv0 = __shfl_xor(send0, 32), recv1 = __shfl_xor(send1, 32);
+                    const float own0 = half ? part[1][0] : part[0][0];
+                    const float own1 = half ? part[1][1] : part[0][1];
+                    // (hidden units with bit 2 clear) + (bit 2 set), then the bias: the oracle's order
+                    const float L0 = ((half ? recv0 : own0) + (half ? own0 : recv0)) + b20;
+                    const float L1 = ((half ? recv1 : own1) + (half ? own1 : recv1)) + b21;
 
-            const int64_t j = j0 + lane;                       // lanes 0-31: strip 0, lanes 32-63: strip 1
-            const int64_t wi = 2 * (int64_t)tj + half;
-            const bool valid = (j > i) && (j < a.n);
-            uint32_t etw = 0;
-            if (wi < a.wpr) etw = a.bits_t[i * a.wpr + wi];
-            const bool e = (etw >> l31) & 1u;
-            float q0, q1;
-            softmax2(L0, L1, q0, q1);
-            const float a0 = q0 * (e ? t0e1 : t0e0);
-            const float c0 = q1 * (e ? t2e1 : t2e0);
-            const float a1 = q0 * (e ? t1e1 : t1e0);
-            const float c1 = q1 * (e ? t3e1 : t3e0);
-            const float p0 = a0 + c0, p1 = a1 + c1;
-            const int64_t rank = i * (2 * a.n - i - 1) / 2 + (j - i - 1);
-            float u;
-            if (a.u) u = valid ? a.u[rank] : 1.0f;
-            else u = u_pair(a.seed, a.step, (uint32_t)i, (uint32_t)j);
-            const bool bit = valid && draw2(u, p0, p1);
-            const unsigned long long m = __ballot(bit);
-            if (lane == 0) {
-                const int64_t w0i = 2 * (int64_t)tj;
-                if (w0i < a.wpr) a.out_upper[i * a.wpr + w0i] = (uint32_t)m;
-                if (w0i + 1 < a.wpr) a.out_upper[i * a.wpr + w0i + 1] = (uint32_t)(m >> 32);
+                    const int64_t j = j0 + lane;                       // lanes 0-31: strip 0, lanes 32-63: strip 1
+                    const int64_t wi = 2 * (int64_t)tj + half;
+                    const bool valid = (j > i) && (j < a.n);
+                    uint32_t etw = 0;
+                    if (wi < a.wpr) etw = a.bits_t[i * a.wpr + wi];
+                    const bool e = (etw >> l31) & 1u;
+                    float q0, q1;
+                    softmax2(L0, L1, q0, q1);
+                    const float a0 = q0 * (e ? a.tab[1] : a.tab[0]);
+                    const float c0 = q1 * (e ? a.tab[5] : a.tab[4]);
+                    const float a1 = q0 * (e ? a.tab[3] : a.tab[2]);
+                    const float c1 = q1 * (e ? a.tab[7] : a.tab[6]);
+                    const float p0 = a0 + c0, p1 = a1 + c1;
+                    const int64_t rank = i * (2 * a.n - i - 1) / 2 + (j - i - 1);
+                    float u;
+                    if (a.u) u = valid ? a.u[rank] : 1.0f;
+                    else u = u_pair(a.seed, a.step, (uint32_t)i, (uint32_t)j);
+                    const bool bit = valid && draw2(u, p0, p1);
+                    const unsigned long long m = __ballot(bit);
+                    if (lane == 0) {
+                        const int64_t w0i = 2 * (int64_t)tj;
+                        if (w0i < a.wpr) a.out_upper[i * a.wpr + w0i] = (uint32_t)m;
+                        if (w0i + 1 < a.wpr) a.out_upper[i * a.wpr + w0i + 1] = (uint32_t)(m >> 32);
+                    }
+#ifndef GM_PAIR_STAMP   // the diagnostic build reuses post_dbg for its stamps
+                    if (valid) {
+                        if (a.logits_dbg) { a.logits_dbg[2 * rank] = L0; a.logits_dbg[2 * rank + 1] = L1; }
+                        if (a.post_dbg) { a.post_dbg[2 * rank] = p0; a.post_dbg[2 * rank + 1] = p1; }
+                    }
+#endif
+                }
             }
-            if (valid) {
-                if (a.logits_dbg) { a.logits_dbg[2 * rank] = L0; a.logits_dbg[2 * rank + 1] = L1; }
-                if (a.post_dbg) { a.post_dbg[2 * rank] = p0; a.post_dbg[2 * rank + 1] = p1; }
+#ifdef GM_PAIR_STAMP
+            st_phase += STAMP() - ph0;
+#endif
+        }
+        // ---- tile hand-over: after this barrier nobody reads the tile's h rows any more; fetch + stage the next tile
+        if (tid == 0) *tile_s = (int)atomicAdd(a.counter, 1u);
+        __syncthreads();
+        t = *tile_s;
+        if (t < a.ntiles) {
+            int lo2 = 0, hi2 = a.nti - 1;
+            while (lo2 < hi2) {
+                const int mid = (lo2 + hi2 + 1) >> 1;
+                if (tile_prefix(mid, width) <= t) lo2 = mid; else hi2 = mid - 1;
+            }
+            const int64_t ni0 = a.row_begin + (int64_t)lo2 * TILE;
+            const int64_t nj0 = (int64_t)(a.tjb + lo2 + (int)(t - tile_prefix(lo2, width))) * TILE;
+            for (int q = tid; q < 2 * TILE * (HE / 4); q += PAIR_THREADS) {
+                const int which = q >> 11;
+                const int r = (q >> 5) & (TILE - 1), c4 = q & 31;
+                const int64_t node = (which ? nj0 : ni0) + r;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (node < a.n) v = *reinterpret_cast<const float4*>(a.h + node * HE + 4 * c4);
+                put_split((which ? hJs : hIs) + r * LDR, c4, v);
             }
         }
+        staged = true;
+        __syncthreads();
     }
+#ifdef GM_PAIR_STAMP
+    if (blockIdx.x == 0 && lane == 0 && (wv == 0 || wv == 4) && a.post_dbg) {
+        float* o = a.post_dbg + 8 * grp;
+        o[0] = (float)st_mma; o[1] = (float)st_epi; o[2] = (float)st_phase; o[3] = (float)st_n; o[4] = (float)st_init;
+    }
+#endif
 }
 
 }  // namespace gm
