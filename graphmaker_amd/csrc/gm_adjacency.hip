@@ -33,10 +33,11 @@ __global__ void k_dense_from_bitmap(int64_t n, int64_t wpr, const uint32_t* __re
 }
 
 // ---------------------------------------------------------------- symmetrize
-// One wave handles 32 rows (lane & 31 = row within the tile; both half-waves do the same rows, different words).
-// For the word (i, w): own bits (j >= i) come from upper[i][w]; bits j < i come from column-word (i>>5) of rows
-// 32w .. 32w+31 -- 32 wave-uniform-per-half loads, i.e. a 32x32 bit-tile transpose.
-__global__ void k_symmetrize(int64_t n, int64_t wpr, const uint32_t* __restrict__ upper, uint32_t* __restrict__ sym) {
+// One block per 32-row tile I; each half-wave owns one output word (i = 32I + lane&31, w) per iteration.
+// Bits j >= i come from upper[i][w]; bits j < i are the transpose of the 32x32 bit tile (rows 32w.., word I):
+// every lane loads one word of that tile and 32 ballots transpose it in registers (lane c keeps ballot number c).
+__global__ void __launch_bounds__(256)
+k_symmetrize(int64_t n, int64_t wpr, const uint32_t* __restrict__ upper, uint32_t* __restrict__ sym) {
     const int lane = threadIdx.x & 63;
     const int li = lane & 31;
     const int half = lane >> 5;
@@ -44,27 +45,30 @@ __global__ void k_symmetrize(int64_t n, int64_t wpr, const uint32_t* __restrict_
     const int64_t i = I * 32 + li;
     const int wavesPerBlock = blockDim.x >> 6;
     const int wv = threadIdx.x >> 6;
-    for (int64_t w = (int64_t)(wv * 2 + half); w < wpr; w += 2 * wavesPerBlock) {
-        uint32_t res = 0;
-        if (i < n && w * 32 < n) {
-            if (w >= I) {
-                uint32_t own = upper[i * wpr + w];
-                if (w == I) own &= ~((1u << li) - 1u);  // keep j >= i
-                res = own;
-            }
-            if (w <= I) {
-                for (int b = 0; b < 32; ++b) {
-                    const int64_t jr = w * 32 + b;
-                    if (jr < i && jr < n) {
-                        uint32_t word = upper[jr * wpr + I];
-                        res |= ((word >> li) & 1u) << b;
-                    }
-                }
-            }
-            const int64_t rem = n - w * 32;  // clear padding bits
-            if (rem < 32) res &= (1u << rem) - 1u;
+    const int64_t wsteps = (wpr + 2 * wavesPerBlock - 1) / (2 * wavesPerBlock);
+    for (int64_t it = 0; it < wsteps; ++it) {            // uniform trip count: the ballots need every lane
+        const int64_t w = it * 2 * wavesPerBlock + wv * 2 + half;
+        const bool inw = w < wpr;
+        uint32_t own = 0, src = 0;
+        if (inw && i < n && w >= I && w * 32 < n) {
+            own = upper[i * wpr + w];
+            if (w == I) own &= ~((1u << li) - 1u);       // keep j >= i
         }
-        if (i < n) sym[i * wpr + w] = res;
+        const int64_t jr = w * 32 + li;                   // row of the source tile this lane fetches
+        if (inw && w <= I && jr < n) src = upper[jr * wpr + I];
+        uint32_t trans = 0;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            const unsigned long long m = __ballot((src >> c) & 1u);
+            const uint32_t mine = half ? (uint32_t)(m >> 32) : (uint32_t)m;
+            if (li == c) trans = mine;
+        }
+        if (w == I) trans &= (1u << li) - 1u;             // keep j < i (w < I: all 32 rows are below i)
+        uint32_t res = own | trans;
+        const int64_t rem = n - w * 32;                   // clear padding bits
+        if (rem <= 0) res = 0;
+        else if (rem < 32) res &= (1u << rem) - 1u;
+        if (inw && i < n) sym[i * wpr + w] = res;
     }
 }
 

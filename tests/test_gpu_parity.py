@@ -338,3 +338,46 @@ def test_no_fallback_on_cpu_tensors():
     from graphmaker_amd._lib import GraphMakerHipError
     with pytest.raises(GraphMakerHipError):
         ops.bitmap_from_dense(torch.zeros((4, 4), dtype=torch.int64))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rank_shards_reproduce_single_gpu_step(dev, world):
+    """The per-rank row ranges of the multi-GPU plan, run one after the other on this GPU into shared buffers (what
+    the all-gathers assemble), give exactly the single-GPU tensors: encoder rows, pair-matrix chunks, attribute rows."""
+    from graphmaker_amd.parallel import ShardPlan
+    ops = _ops()
+    cfg, g, model, *_ = _models("sync_mid", dev)
+    N, F, seed, T = cfg["N"], cfg["F"], cfg["seed"], cfg["T"]
+    Y32 = t_(g["Y"], dev)
+    ref_bits, dense = _bits_from_nz(g[f"e{T}_E_in_nz"], N)
+    bits = bits_t(ref_bits, dev)
+    A_t = ops.adjacency_from_bitmap(bits, N)
+    x_in = t_(g[f"e{T}_X_in"], dev)
+    X_oh = ops.onehot_from_x(x_in)
+    t_float = torch.tensor([1.0], dtype=torch.float32, device=dev)
+    tab_E, tab_X = model.step_tables(T)
+    enc, pred_X = model.graph_encoder.pred_E.gnn_encoder, model.graph_encoder.pred_X
+    W1, b1, W2, b2 = model.graph_encoder.pred_E.pair_params()
+    h_full = enc(t_float, X_oh, Y32, A_t)
+    up_full = ops.pair_score_sample(h_full, W1, b1, W2, b2, bits, tab_E, seed=seed, step=T)
+    lg_full = pred_X._run(t_float, X_oh, Y32, A_t)
+    xs_full, _ = ops.attr_posterior_sample(lg_full, x_in, t_(tab_X, dev), seed=seed, step=T)
+
+    h = torch.full_like(h_full, float("nan"))
+    up = torch.zeros_like(up_full)
+    lg = torch.full_like(lg_full, float("nan"))
+    xs = torch.full_like(xs_full, 255)
+    for r in range(world):
+        plan = ShardPlan.make(N, world, r)
+        enc._run(t_float, X_oh, Y32, A_t, rows=plan.node_range(), out=h)
+        pred_X._run(t_float, X_oh, Y32, A_t, rows=plan.node_range(), out=lg)
+    assert torch.equal(h, h_full) and torch.equal(lg, lg_full)
+    for r in range(world):
+        plan = ShardPlan.make(N, world, r)
+        for r0, r1 in plan.pair_chunks():
+            if r1 > r0:
+                ops.pair_score_sample(h, W1, b1, W2, b2, bits, tab_E, seed=seed, step=T, row_begin=r0, row_end=r1, out_upper=up)
+        ops.attr_posterior_sample(lg, x_in, t_(tab_X, dev), seed=seed, step=T, rows=plan.node_range(), x_s=xs,
+                                  want_onehot=False)
+    assert torch.equal(ops.symmetrize_upper(up, N), ops.symmetrize_upper(up_full, N))
+    assert torch.equal(xs, xs_full)
