@@ -79,22 +79,27 @@ def cpu_baseline(wl, model, state, budget_rows=768, threads=None):
     t0 = time.perf_counter()
     rp, ci = orc.csr_from_bitmap(bits_np, n)
     h = towerE.forward(np.float32(1.0), oh_np, y_np, rp, ci)
-    t1 = time.perf_counter()
-    rows = min(budget_rows, n)
+    t_tower_e = time.perf_counter() - t0
+    # size the pair-stage sample for ~12 s of host work: probe 64 rows (untimed), then pick the row count
+    tp = time.perf_counter()
+    orc.pair_score_sample(n, h, pair, bits_np, tab_E, seed=0, step=T, row_begin=0, row_end=min(64, n))
+    rate = sum(n - 1 - i for i in range(min(64, n))) / max(time.perf_counter() - tp, 1e-6)
+    rows = min(n, max(budget_rows, int(12.0 * rate / n)))
+    t0 = time.perf_counter()
     orc.pair_score_sample(n, h, pair, bits_np, tab_E, seed=0, step=T, row_begin=0, row_end=rows)
-    t2 = time.perf_counter()
+    t_pair = time.perf_counter() - t0
+    t0 = time.perf_counter()
     logits = towerX.forward(np.float32(1.0), oh_np, y_np, rp, ci)
     orc.attr_posterior_sample(logits, x_np, tab_X, seed=0, step=T)
-    t3 = time.perf_counter()
+    t_tower_x = time.perf_counter() - t0
     P = n * (n - 1) // 2
     p_sample = sum(n - 1 - i for i in range(rows))
-    t_pair_full = (t2 - t1) * P / p_sample
-    step_s = (t1 - t0) + t_pair_full + (t3 - t2)
+    step_s = t_tower_e + t_pair * P / p_sample + t_tower_x
     return {"value": 1.0 / step_s, "unit": "steps/s", "cores": orc.get_threads(), "kind": "port",
-            "pair_scores_per_sec": p_sample / (t2 - t1),
-            "sample": f"edge+node towers and attribute draw on all {n} nodes ({t1 - t0 + t3 - t2:.1f} s); pair stage on rows "
-                      f"[0,{rows}) = {p_sample} of {P} pairs ({t2 - t1:.1f} s), extrapolated by pair count; encoder "
-                      "hoisted once per step (the reference re-runs it per 32768-pair batch)"}
+            "pair_scores_per_sec": p_sample / t_pair,
+            "sample": f"CSR + edge tower ({t_tower_e:.1f} s) and node tower + attribute draw ({t_tower_x:.1f} s) on all {n} "
+                      f"nodes; pair stage on rows [0,{rows}) = {p_sample} of {P} pairs ({t_pair:.1f} s), extrapolated by "
+                      "pair count; encoder hoisted once per step (the reference re-runs it per 32768-pair batch)"}
 
 
 def main():
@@ -163,6 +168,12 @@ def main():
     pairs_here = P if plan is None else plan.pairs_of(rank)
     achieved = FLOP_PER_PAIR * pairs_here / (pair_ms * 1e-3) / 1e12
 
+    traffic = None          # HBM bytes per launch of the pair kernel, from the committed PMC passes of this same command
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_pmc_summary.json")) as fh:
+            traffic = json.load(fh)["_derived"]["pair_kernel_hbm_traffic_bytes_per_launch"] if world == 1 else None
+    except Exception:
+        traffic = None
     if rank == 0:
         res = {
             "metric": "denoising steps/sec (amazon_computer Sync step); pair-scores/sec in pair_scores_per_sec",
@@ -180,7 +191,7 @@ def main():
             "phases_ms_rank0": phases,
             "roofline": {"kernel": "gm::k_pair_score_sample", "bound": "mfma", "achieved": achieved,
                          "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
-                         "traffic": None, "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch_rank0": pairs_here,
+                         "traffic": traffic, "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch_rank0": pairs_here,
                          "launch_ms": pair_ms},
         }
         if not args.no_cpu_baseline and world == 1:
