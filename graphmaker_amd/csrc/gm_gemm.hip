@@ -17,7 +17,11 @@ namespace gm {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 16;
+#ifndef GM_GEMM_BK
+#define GM_GEMM_BK 16
+#endif
+constexpr int BM = 128, BN = 128, BK = GM_GEMM_BK;
+constexpr int KPT = BK / 2;   // k values staged per thread and operand (row = tid/2, k-half = tid%2)
 constexpr int LDT = BM + 4;  // padded k-row length (floats)
 
 // Each thread stages 8 consecutive k of one tile row: row = tid/2, k-half = tid%2.
@@ -58,6 +62,25 @@ __device__ __forceinline__ void load_row8(const float* __restrict__ base, int64_
     }
 }
 
+// unguarded twin of load_row8 for tiles that lie fully inside K (rows are clamped by the caller): straight-line
+// vector loads, so all of a tile's loads are in flight together instead of one branch + wait per vector.
+template <int VEC>
+__device__ __forceinline__ void load_row8_fast(const float* __restrict__ p, float (&r)[8]) {
+    if (VEC == 4) {
+        const float4 v0 = *reinterpret_cast<const float4*>(p), v1 = *reinterpret_cast<const float4*>(p + 4);
+        r[0] = v0.x; r[1] = v0.y; r[2] = v0.z; r[3] = v0.w; r[4] = v1.x; r[5] = v1.y; r[6] = v1.z; r[7] = v1.w;
+    } else if (VEC == 2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float2 v = *reinterpret_cast<const float2*>(p + 2 * q);
+            r[2 * q] = v.x; r[2 * q + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r[q] = p[q];
+    }
+}
+
 template <int VEC>
 __global__ void __launch_bounds__(256, 2)
 k_linear(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
@@ -70,10 +93,16 @@ k_linear(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t l
     const int wm = wv >> 1, wn = wv & 1;  // wave position in the 2x2 grid
     const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
 
-    const int srow = tid >> 1, skh = (tid & 1) * 8;
-    float ra[8], rb[8];
-    load_row8<VEC>(A, lda, m0 + srow, M, skh, K, ra);
-    load_row8<VEC>(W, ldw, n0 + srow, N, skh, K, rb);
+    const int srow = tid >> 1, skh = (tid & 1) * KPT;
+    // rows past the edge are clamped, not zeroed: they only feed output rows/columns that are never stored
+    const float* pa = A + (m0 + srow < M ? m0 + srow : M - 1) * lda + skh;
+    const float* pw = W + (n0 + srow < N ? n0 + srow : N - 1) * ldw + skh;
+    float ra[KPT / 8][8], rb[KPT / 8][8];
+#pragma unroll
+    for (int c = 0; c < KPT / 8; ++c) {
+        load_row8<VEC>(A, lda, m0 + srow, M, skh + 8 * c, K, ra[c]);
+        load_row8<VEC>(W, ldw, n0 + srow, N, skh + 8 * c, K, rb[c]);
+    }
 
     floatx16 acc[2][2];
 #pragma unroll
@@ -86,14 +115,25 @@ k_linear(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t l
     for (int64_t k0 = 0; k0 < K; k0 += BK) {
         __syncthreads();  // previous tile's fragment reads are done
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            As[(skh + q) * LDT + srow] = ra[q];
-            Bs[(skh + q) * LDT + srow] = rb[q];
-        }
+        for (int c = 0; c < KPT / 8; ++c)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                As[(skh + 8 * c + q) * LDT + srow] = ra[c][q];
+                Bs[(skh + 8 * c + q) * LDT + srow] = rb[c][q];
+            }
         __syncthreads();
-        if (k0 + BK < K) {  // next tile in flight while this one is multiplied
-            load_row8<VEC>(A, lda, m0 + srow, M, k0 + BK + skh, K, ra);
-            load_row8<VEC>(W, ldw, n0 + srow, N, k0 + BK + skh, K, rb);
+        if (k0 + 2 * BK <= K) {  // next tile (fully inside K) in flight while this one is multiplied
+#pragma unroll
+            for (int c = 0; c < KPT / 8; ++c) {
+                load_row8_fast<VEC>(pa + k0 + BK + 8 * c, ra[c]);
+                load_row8_fast<VEC>(pw + k0 + BK + 8 * c, rb[c]);
+            }
+        } else if (k0 + BK < K) {  // ragged last tile: guarded loads, zeros beyond K
+#pragma unroll
+            for (int c = 0; c < KPT / 8; ++c) {
+                load_row8<VEC>(A, lda, m0 + srow, M, k0 + BK + skh + 8 * c, K, ra[c]);
+                load_row8<VEC>(W, ldw, n0 + srow, N, k0 + BK + skh + 8 * c, K, rb[c]);
+            }
         }
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ++ks) {
