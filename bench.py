@@ -189,8 +189,8 @@ def main():
                                    f"hidden 512/64/{wl['gnn_E']['hidden_t']}/128, L=2; E_t = prior draw, nnz={nnz}; "
                                    f"all P={P} unordered pairs (N^2 equivalent {2 * P + n})",
                        "pairs_per_step": P, "parallelism": "single GPU" if world == 1 else
-                       f"{world} ranks: folded row chunks of the pair matrix, row-sharded tower output MLPs, "
-                       "3 all-gathers (h, E rows, X)"},
+                       f"{world} ranks: folded row chunks of the pair matrix, row-sharded towers, all-gathers of "
+                       "layer inputs, h, E rows and X over RCCL"},
             "pair_scores_per_sec": P / (elapsed / args.steps),
             "pair_phase_scores_per_sec": pairs_here * (world if plan else 1) / (pair_ms * 1e-3),
             "phases_ms_rank0": phases,

@@ -65,6 +65,29 @@ __device__ __forceinline__ void put_split(float* row, int c4, float4 v) {
     *reinterpret_cast<float2*>(row + 64 + 2 * c4) = make_float2(v.y, v.w);
 }
 
+// Stage the 64 h_i rows and 64 h_j rows of a tile: 8 float4 per thread, all loads issued before the first LDS write.
+// Rows past n are clamped to n-1, not zeroed: they only feed pairs that are masked (j >= n) or skipped (i >= n).
+__device__ __forceinline__ void stage_tile(const float* __restrict__ h, int64_t n, int64_t i0, int64_t j0, float* hIs,
+                                           float* hJs, int tid) {
+    float4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int q = tid + k * PAIR_THREADS;
+        const int which = q >> 11;             // 0: i rows, 1: j rows
+        const int r = (q >> 5) & (TILE - 1), c4 = q & 31;
+        int64_t node = (which ? j0 : i0) + r;
+        node = node < n ? node : n - 1;
+        v[k] = *reinterpret_cast<const float4*>(h + node * HE + 4 * c4);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int q = tid + k * PAIR_THREADS;
+        const int which = q >> 11;
+        const int r = (q >> 5) & (TILE - 1), c4 = q & 31;
+        put_split((which ? hJs : hIs) + r * LDR, c4, v[k]);
+    }
+}
+
 struct Frag {
     float4 w[4];
     float4 hi, ha, hb;
@@ -152,14 +175,7 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
         const int64_t j0 = (int64_t)tj * TILE;
 
         if (!staged) {   // first tile of this workgroup; later tiles are staged at the hand-over below
-            for (int q = tid; q < 2 * TILE * (HE / 4); q += PAIR_THREADS) {
-                const int which = q >> 11;             // 0: i rows, 1: j rows
-                const int r = (q >> 5) & (TILE - 1), c4 = q & 31;
-                const int64_t node = (which ? j0 : i0) + r;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (node < a.n) v = *reinterpret_cast<const float4*>(a.h + node * HE + 4 * c4);
-                put_split((which ? hJs : hIs) + r * LDR, c4, v);
-            }
+            stage_tile(a.h, a.n, i0, j0, hIs, hJs, tid);
             __syncthreads();
         }
 
@@ -324,14 +340,7 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
             }
             const int64_t ni0 = a.row_begin + (int64_t)lo2 * TILE;
             const int64_t nj0 = (int64_t)(a.tjb + lo2 + (int)(t - tile_prefix(lo2, width))) * TILE;
-            for (int q = tid; q < 2 * TILE * (HE / 4); q += PAIR_THREADS) {
-                const int which = q >> 11;
-                const int r = (q >> 5) & (TILE - 1), c4 = q & 31;
-                const int64_t node = (which ? nj0 : ni0) + r;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (node < a.n) v = *reinterpret_cast<const float4*>(a.h + node * HE + 4 * c4);
-                put_split((which ? hJs : hIs) + r * LDR, c4, v);
-            }
+            stage_tile(a.h, a.n, ni0, nj0, hIs, hJs, tid);
         }
         staged = true;
         __syncthreads();

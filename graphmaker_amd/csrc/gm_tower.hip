@@ -70,74 +70,144 @@ extern "C" int gm_tower_workspace_bytes(const gm_tower_dims* dims, int64_t n, si
         if (_rc != GM_OK) return _rc; \
     } while (0)
 
-extern "C" int gm_tower_forward(const gm_tower_dims* d, const float* const* P, int64_t n, const float* t_float,
-                                const float* X_one_hot, const int32_t* Y, const int32_t* rowptr, const int32_t* colidx,
-                                float* out, float* hcat_out, int64_t out_row_begin, int64_t out_row_end, void* workspace,
-                                size_t workspace_bytes, gm_stream_t stream) {
+namespace {
+
+struct TowerCtx {
+    const gm_tower_dims* d;
+    const float* const* P;
+    int64_t n;
+    gm_stream_t stream;
+    hipStream_t s;
+    float *hcat, *agg, *mid, *tmpX, *ht0, *ht1;
+    int ht, hX, hY, nl;
+    int64_t Hc, ka, offY, offT;
+};
+
+int tower_ctx(TowerCtx& c, const gm_tower_dims* d, const float* const* P, int64_t n, void* workspace, size_t workspace_bytes,
+              gm_stream_t stream) {
     if (int rc = check_dims(d, n)) return rc;
-    GM_REQUIRE(P && t_float && X_one_hot && Y && out && workspace, "null pointer");
-    GM_REQUIRE(d->is_mlp || (rowptr && (colidx || true)), "GNN tower needs a CSR adjacency");
-    GM_REQUIRE(0 <= out_row_begin && out_row_begin <= out_row_end && out_row_end <= n, "bad output row range [%lld,%lld)",
-               (long long)out_row_begin, (long long)out_row_end);
+    GM_REQUIRE(P && workspace, "null pointer");
     const TowerWs L = tower_layout(d, n);
     GM_REQUIRE(workspace_bytes >= L.total, "workspace too small: need %zu bytes, got %zu", L.total, workspace_bytes);
     GM_REQUIRE(aligned(workspace, 256), "workspace must be 256-byte aligned");
     const int nparams = 9 + 8 * d->num_layers + 4;
     for (int i = 0; i < nparams; ++i) GM_REQUIRE(P[i], "parameter %d is null", i);
-
-    hipStream_t s = as_stream(stream);
     char* ws = static_cast<char*>(workspace);
-    float* hcat = reinterpret_cast<float*>(ws + L.hcat);
-    float* agg = reinterpret_cast<float*>(ws + L.agg);
-    float* mid = reinterpret_cast<float*>(ws + L.mid);
-    float* tmpX = reinterpret_cast<float*>(ws + L.tmpX);
-    float* ht0 = reinterpret_cast<float*>(ws + L.ht0);
-    float* ht1 = reinterpret_cast<float*>(ws + L.ht1);
+    c.d = d; c.P = P; c.n = n; c.stream = stream; c.s = as_stream(stream);
+    c.hcat = reinterpret_cast<float*>(ws + L.hcat);
+    c.agg = reinterpret_cast<float*>(ws + L.agg);
+    c.mid = reinterpret_cast<float*>(ws + L.mid);
+    c.tmpX = reinterpret_cast<float*>(ws + L.tmpX);
+    c.ht0 = reinterpret_cast<float*>(ws + L.ht0);
+    c.ht1 = reinterpret_cast<float*>(ws + L.ht1);
+    c.ht = d->hidden_t; c.hX = d->hidden_X; c.hY = d->hidden_Y; c.nl = d->num_layers;
+    c.Hc = (int64_t)(c.nl + 1) * (c.hX + c.hY) + c.ht;
+    c.ka = c.hX + c.hY + c.ht;
+    c.offY = (int64_t)(c.nl + 1) * c.hX;
+    c.offT = (int64_t)(c.nl + 1) * (c.hX + c.hY);
+    return GM_OK;
+}
 
-    const int ht = d->hidden_t, hX = d->hidden_X, hY = d->hidden_Y, nl = d->num_layers;
-    const int64_t Hc = (int64_t)(nl + 1) * (hX + hY) + ht;
-    const int64_t ka = hX + hY + ht;
-    const int64_t offY = (int64_t)(nl + 1) * hX, offT = (int64_t)(nl + 1) * (hX + hY);
+// input projections for node rows [r0,r1): mlp_in_t, mlp_in_X, emb_Y (model/gnn.py:116-127,153-155) -> h^0 slices of hcat
+int tower_input(const TowerCtx& c, const float* t_float, const float* X_one_hot, const int32_t* Y, int64_t r0, int64_t r1) {
+    const float* const* P = c.P;
+    const int64_t rows = r1 - r0;
+    GM_TRY(gm_linear(1, c.ht, 1, t_float, 1, P[0], 1, P[1], c.ht0, c.ht, 1, c.stream));
+    GM_TRY(gm_linear(1, c.ht, c.ht, c.ht0, c.ht, P[2], c.ht, P[3], c.ht1, c.ht, 1, c.stream));
+    if (rows <= 0) return GM_OK;
+    const int64_t in_X = c.d->in_X;
+    GM_TRY(launch_broadcast_row(rows, c.ht, c.ht1, c.hcat + r0 * c.Hc + c.offT, c.Hc, c.s));
+    GM_TRY(launch_broadcast_row(rows, c.ht, c.ht1, c.agg + r0 * c.ka + c.hX + c.hY, c.ka, c.s));
+    GM_TRY(gm_linear(rows, c.hX, in_X, X_one_hot + r0 * in_X, in_X, P[4], in_X, P[5], c.tmpX + r0 * c.hX, c.hX, 1, c.stream));
+    GM_TRY(gm_linear(rows, c.hX, c.hX, c.tmpX + r0 * c.hX, c.hX, P[6], c.hX, P[7], c.hcat + r0 * c.Hc, c.Hc, 1, c.stream));
+    GM_TRY(launch_gather_rows(rows, c.hY, Y + r0, P[8], c.hY, c.hcat + r0 * c.Hc + c.offY, c.Hc, c.s));
+    return GM_OK;
+}
 
-    // mlp_in_t (model/gnn.py:116-120,153)
-    GM_TRY(gm_linear(1, ht, 1, t_float, 1, P[0], 1, P[1], ht0, ht, 1, stream));
-    GM_TRY(gm_linear(1, ht, ht, ht0, ht, P[2], ht, P[3], ht1, ht, 1, stream));
-    GM_TRY(launch_broadcast_row(n, ht, ht1, hcat + offT, Hc, s));
-    // mlp_in_X (:121-126,154)
-    GM_TRY(gm_linear(n, hX, d->in_X, X_one_hot, d->in_X, P[4], d->in_X, P[5], tmpX, hX, 1, stream));
-    GM_TRY(gm_linear(n, hX, hX, tmpX, hX, P[6], hX, P[7], hcat, Hc, 1, stream));
-    // emb_Y (:127,155)
-    GM_TRY(launch_gather_rows(n, hY, Y, P[8], hY, hcat + offY, Hc, s));
-
-    GM_TRY(launch_broadcast_row(n, ht, ht1, agg + hX + hY, ka, s));
-    for (int l = 0; l < nl; ++l) {
-        const float* const* Q = P + 9 + 8 * l;
-        const float* hXl = hcat + (int64_t)l * hX;
-        const float* hYl = hcat + offY + (int64_t)l * hY;
-        if (!d->is_mlp) {
-            // GNNLayer.forward (:60-61): A @ [h_X | h_Y]; A @ h_Y is its last hY columns
-            GM_TRY(gm_spmm_mean(n, rowptr, colidx, hXl, Hc, hX, agg, ka, stream));
-            GM_TRY(gm_spmm_mean(n, rowptr, colidx, hYl, Hc, hY, agg + hX, ka, stream));
-        } else {
-            // MLPLayer.forward (:387-392): no aggregation
-            GM_TRY(launch_copy2d(n, hX, hXl, Hc, agg, ka, s));
-            GM_TRY(launch_copy2d(n, hY, hYl, Hc, agg + hX, ka, s));
-        }
-        float* hXn = hcat + (int64_t)(l + 1) * hX;
-        float* hYn = hcat + offY + (int64_t)(l + 1) * hY;
-        GM_TRY(gm_linear(n, hX, ka, agg, ka, Q[0], ka, Q[1], hXn, Hc, 1, stream));       // update_X (:27-32,67)
-        GM_TRY(gm_layernorm(n, hX, hXn, Hc, Q[2], Q[3], 1e-5f, stream));
-        GM_TRY(gm_linear(n, hY, hY, agg + hX, ka, Q[4], hY, Q[5], hYn, Hc, 1, stream));   // update_Y (:33-38,68)
-        GM_TRY(gm_layernorm(n, hY, hYn, Hc, Q[6], Q[7], 1e-5f, stream));
+// layer l for node rows [r0,r1).  The aggregation reads h^l of ALL nodes: from hcat (src == NULL: single GPU, every
+// row is local) or from `src`, an (n, hX+hY) buffer [h_X^l | h_Y^l] that an all-gather assembled.
+int tower_layer(const TowerCtx& c, int l, const int32_t* rowptr, const int32_t* colidx, const float* src, int64_t r0, int64_t r1) {
+    const int64_t rows = r1 - r0;
+    if (rows <= 0) return GM_OK;
+    const float* const* Q = c.P + 9 + 8 * l;
+    const float* hXl = src ? src : c.hcat + (int64_t)l * c.hX;
+    const float* hYl = src ? src + c.hX : c.hcat + c.offY + (int64_t)l * c.hY;
+    const int64_t ld = src ? (int64_t)(c.hX + c.hY) : c.Hc;
+    float* agg = c.agg + r0 * c.ka;
+    if (!c.d->is_mlp) {
+        // GNNLayer.forward (:60-61): A @ [h_X | h_Y]; A @ h_Y is its last hY columns
+        GM_TRY(gm_spmm_mean(rows, rowptr + r0, colidx, hXl, ld, c.hX, agg, c.ka, c.stream));
+        GM_TRY(gm_spmm_mean(rows, rowptr + r0, colidx, hYl, ld, c.hY, agg + c.hX, c.ka, c.stream));
+    } else {
+        // MLPLayer.forward (:387-392): no aggregation, row-local
+        GM_TRY(launch_copy2d(rows, c.hX, c.hcat + r0 * c.Hc + (int64_t)l * c.hX, c.Hc, agg, c.ka, c.s));
+        GM_TRY(launch_copy2d(rows, c.hY, c.hcat + r0 * c.Hc + c.offY + (int64_t)l * c.hY, c.Hc, agg + c.hX, c.ka, c.s));
     }
-    // mlp_out (:138-142,165-176)
-    const float* const* O = P + 9 + 8 * nl;
-    const int64_t rb = out_row_begin, rows = out_row_end - out_row_begin;
-    if (rows > 0) {
-        GM_TRY(gm_linear(rows, Hc, Hc, hcat + rb * Hc, Hc, O[0], Hc, O[1], mid + rb * Hc, Hc, 1, stream));
-        GM_TRY(gm_linear(rows, d->out_size, Hc, mid + rb * Hc, Hc, O[2], Hc, O[3], out + rb * d->out_size, d->out_size, 0,
-                         stream));
+    float* hXn = c.hcat + r0 * c.Hc + (int64_t)(l + 1) * c.hX;
+    float* hYn = c.hcat + r0 * c.Hc + c.offY + (int64_t)(l + 1) * c.hY;
+    GM_TRY(gm_linear(rows, c.hX, c.ka, agg, c.ka, Q[0], c.ka, Q[1], hXn, c.Hc, 1, c.stream));        // update_X (:27-32,67)
+    GM_TRY(gm_layernorm(rows, c.hX, hXn, c.Hc, Q[2], Q[3], 1e-5f, c.stream));
+    GM_TRY(gm_linear(rows, c.hY, c.hY, agg + c.hX, c.ka, Q[4], c.hY, Q[5], hYn, c.Hc, 1, c.stream));  // update_Y (:33-38,68)
+    GM_TRY(gm_layernorm(rows, c.hY, hYn, c.Hc, Q[6], Q[7], 1e-5f, c.stream));
+    return GM_OK;
+}
+
+// mlp_out (:138-142,165-176) for rows [r0,r1)
+int tower_output(const TowerCtx& c, float* out, int64_t r0, int64_t r1) {
+    const int64_t rows = r1 - r0;
+    if (rows <= 0) return GM_OK;
+    const float* const* O = c.P + 9 + 8 * c.nl;
+    const int64_t os = c.d->out_size;
+    GM_TRY(gm_linear(rows, c.Hc, c.Hc, c.hcat + r0 * c.Hc, c.Hc, O[0], c.Hc, O[1], c.mid + r0 * c.Hc, c.Hc, 1, c.stream));
+    GM_TRY(gm_linear(rows, os, c.Hc, c.mid + r0 * c.Hc, c.Hc, O[2], c.Hc, O[3], out + r0 * os, os, 0, c.stream));
+    return GM_OK;
+}
+
+}  // namespace
+
+extern "C" int gm_tower_forward(const gm_tower_dims* d, const float* const* P, int64_t n, const float* t_float,
+                                const float* X_one_hot, const int32_t* Y, const int32_t* rowptr, const int32_t* colidx,
+                                float* out, float* hcat_out, int64_t out_row_begin, int64_t out_row_end, void* workspace,
+                                size_t workspace_bytes, gm_stream_t stream) {
+    TowerCtx c;
+    if (int rc = tower_ctx(c, d, P, n, workspace, workspace_bytes, stream)) return rc;
+    GM_REQUIRE(t_float && X_one_hot && Y && out, "null pointer");
+    GM_REQUIRE(d->is_mlp || d->num_layers == 0 || (rowptr && colidx), "GNN tower needs a CSR adjacency");
+    GM_REQUIRE(0 <= out_row_begin && out_row_begin <= out_row_end && out_row_end <= n, "bad output row range [%lld,%lld)",
+               (long long)out_row_begin, (long long)out_row_end);
+    GM_TRY(tower_input(c, t_float, X_one_hot, Y, 0, n));
+    for (int l = 0; l < c.nl; ++l) GM_TRY(tower_layer(c, l, rowptr, colidx, nullptr, 0, n));
+    GM_TRY(tower_output(c, out, out_row_begin, out_row_end));
+    if (hcat_out) GM_HIP(hipMemcpyAsync(hcat_out, c.hcat, sizeof(float) * (size_t)(n * c.Hc), hipMemcpyDeviceToDevice, c.s));
+    return GM_OK;
+}
+
+extern "C" int gm_tower_stage(const gm_tower_dims* d, const float* const* P, int64_t n, int stage, int64_t row_begin,
+                              int64_t row_end, const float* t_float, const float* X_one_hot, const int32_t* Y,
+                              const int32_t* rowptr, const int32_t* colidx, const float* layer_src, float* layer_dst,
+                              float* out, void* workspace, size_t workspace_bytes, gm_stream_t stream) {
+    TowerCtx c;
+    if (int rc = tower_ctx(c, d, P, n, workspace, workspace_bytes, stream)) return rc;
+    GM_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= n, "bad row range [%lld,%lld)", (long long)row_begin,
+               (long long)row_end);
+    GM_REQUIRE(stage >= -1 && stage <= c.nl, "stage %d out of range [-1,%d]", stage, c.nl);
+    if (stage == -1) {
+        GM_REQUIRE(t_float && X_one_hot && Y, "null pointer");
+        GM_TRY(tower_input(c, t_float, X_one_hot, Y, row_begin, row_end));
+    } else if (stage < c.nl) {
+        GM_REQUIRE(d->is_mlp || (rowptr && colidx), "GNN tower needs a CSR adjacency");
+        GM_TRY(tower_layer(c, stage, rowptr, colidx, layer_src, row_begin, row_end));
+    } else {
+        GM_REQUIRE(out, "null pointer");
+        GM_TRY(tower_output(c, out, row_begin, row_end));
     }
-    if (hcat_out) GM_HIP(hipMemcpyAsync(hcat_out, hcat, sizeof(float) * (size_t)(n * Hc), hipMemcpyDeviceToDevice, s));
+    // hand this rank's rows of [h_X^s | h_Y^s] (s = stage+1, the slices just written) to the caller for the all-gather
+    if (layer_dst && stage < c.nl && row_end > row_begin) {
+        const int sl = stage + 1;
+        const int64_t rows = row_end - row_begin, w = c.hX + c.hY;
+        GM_TRY(launch_copy2d(rows, c.hX, c.hcat + row_begin * c.Hc + (int64_t)sl * c.hX, c.Hc, layer_dst + row_begin * w, w, c.s));
+        GM_TRY(launch_copy2d(rows, c.hY, c.hcat + row_begin * c.Hc + c.offY + (int64_t)sl * c.hY, c.Hc,
+                             layer_dst + row_begin * w + c.hX, w, c.s));
+    }
     return GM_OK;
 }

@@ -146,6 +146,14 @@ class BaseModel(nn.Module):
     def phase(self, name):
         return BaseModel._Phase(self, name)
 
+    def _buf(self, name, shape, dtype, device):
+        """Step-persistent scratch tensors of the sharded path (buffers that collectives touch are kept, not re-made)."""
+        cache = self.__dict__.setdefault("_bufs", {})
+        key = (name, tuple(shape), dtype, device)
+        if key not in cache:
+            cache[key] = torch.empty(shape, dtype=dtype, device=device)
+        return cache[key]
+
     def enable_phase_timing(self, on=True):
         self._prof = {} if on else None
 
@@ -192,9 +200,9 @@ class BaseModel(nn.Module):
             if plan is None:
                 h = enc(t_float, X_one_hot, Y32, A_t)
             else:
-                h_pad = torch.empty((plan.world * plan.node_rows, enc._dims.out_size), dtype=torch.float32,
-                                    device=X_one_hot.device)
-                enc._run(t_float, X_one_hot, Y32, A_t, rows=plan.node_range(), out=h_pad[:n])
+                h_pad = self._buf("h_pad", (plan.world * plan.node_rows, enc._dims.out_size), torch.float32,
+                                  X_one_hot.device)
+                enc._run_sharded(t_float, X_one_hot, Y32, A_t, plan, group, h_pad[:n], parallel.all_gather_node_rows)
         if plan is not None:
             with self.phase("allgather_h"):
                 h = parallel.all_gather_node_rows(plan, h_pad, group)[:n]
@@ -215,6 +223,17 @@ class BaseModel(nn.Module):
             bits_s = ops.symmetrize_upper(upper, n)
         return A_t, bits_s
 
+    def _logits_fn(self, pred_X, t_float, x_onehot, Y32, A_t, plan, group):
+        """rows -> (n, 2F) attribute logits valid on `rows` (all rows on a single GPU)."""
+        if plan is None:
+            return lambda rows: pred_X._run(t_float, x_onehot, Y32, A_t)
+        n = self.num_nodes
+
+        def sharded(rows):
+            out = self._buf("logits", (n, pred_X._dims.out_size), torch.float32, x_onehot.device)
+            return pred_X._run_sharded(t_float, x_onehot, Y32, A_t, plan, group, out, parallel.all_gather_node_rows)
+        return sharded
+
     def _attribute_draw(self, logits_fn, x, tab_X, seed, step, u=None, plan=None, group=None):
         """softmax + posterior + sample_X (model/diffusion.py:879-895) on this rank's node rows, then replicate.
         logits_fn(rows) -> (n, 2F) logits valid on `rows`."""
@@ -227,12 +246,12 @@ class BaseModel(nn.Module):
         if plan is None:
             with self.phase("attr"):
                 return ops.attr_posterior_sample(logits, x, tabX_dev, seed=seed, step=step, u=u)
-        x_pad = torch.empty((plan.world * plan.node_rows, x.shape[1]), dtype=torch.uint8, device=dev)
+        x_pad = self._buf("x_pad", (plan.world * plan.node_rows, x.shape[1]), torch.uint8, dev)
         with self.phase("attr"):
             ops.attr_posterior_sample(logits, x, tabX_dev, seed=seed, step=step, u=u, rows=rows, x_s=x_pad[:n],
                                       want_onehot=False)
         with self.phase("allgather_X"):
-            x_s = parallel.all_gather_node_rows(plan, x_pad, group)[:n]
+            x_s = parallel.all_gather_node_rows(plan, x_pad, group)[:n].clone()      # x_pad is reused by the next step
         with self.phase("attr"):
             return x_s, ops.onehot_from_x(x_s)
 
@@ -275,7 +294,7 @@ class ModelSync(BaseModel):
         A_t, bits_s = self._structure_step(self.graph_encoder.pred_E, t_float, x_onehot, Y32, bits_t, tab_E, seed, t,
                                            u=uE, plan=plan, group=group)
         pred_X = self.graph_encoder.pred_X                                      # A_t of E_t, not E_s (:875-878)
-        x_s, oh_s = self._attribute_draw(lambda rows: pred_X._run(t_float, x_onehot, Y32, A_t, rows=rows), x, tab_X,
+        x_s, oh_s = self._attribute_draw(self._logits_fn(pred_X, t_float, x_onehot, Y32, A_t, plan, group), x, tab_X,
                                          seed, t, u=uX, plan=plan, group=group)
         return x_s, oh_s, bits_s
 
@@ -331,7 +350,7 @@ class ModelAsync(BaseModel):
         t_float = torch.tensor([t / self.T_X], dtype=torch.float32).to(dev)
         pred_X = self.graph_encoder.pred_X
         uX = uniforms.get(("X", t)) if uniforms else None
-        return self._attribute_draw(lambda rows: pred_X._run(t_float, x_onehot, Y32, None, rows=rows), x, self.table_X(t),
+        return self._attribute_draw(self._logits_fn(pred_X, t_float, x_onehot, Y32, None, plan, group), x, self.table_X(t),
                                     seed, t, u=uX, plan=plan, group=group)
 
     @torch.no_grad()

@@ -91,6 +91,34 @@ class _TowerBase(nn.Module):
                                  self._workspace(n, X.device), want_hcat=want_hcat, rows=rows, out=out)
 
 
+    def _run_sharded(self, t_float, X_t_one_hot, Y_real, A_t, plan, group, out, gather):
+        """Row-sharded forward for the one-process-per-GPU decomposition: this rank computes node rows
+        plan.node_range() of every stage; before each message-passing layer the [h_X | h_Y] rows of all ranks are
+        replicated by `gather` (parallel.all_gather_node_rows).  Writes rows node_range() of `out` (n, out_size)."""
+        n = X_t_one_hot.shape[0]
+        X = X_t_one_hot if X_t_one_hot.is_contiguous() else X_t_one_hot.contiguous()
+        Y32 = (Y_real if Y_real.dtype == torch.int32 else Y_real.to(torch.int32)).contiguous()
+        t = t_float.reshape(1).to(torch.float32)
+        d, ptrs, ws = self._dims, self._param_ptrs(), self._workspace(n, X.device)
+        rows = plan.node_range()
+        need_gather = not self._is_mlp and d.num_layers > 0
+        width = d.hidden_X + d.hidden_Y
+        bufs = [None, None]
+        if need_gather:   # persistent across steps: the collectives' stream keeps references, re-allocating churns
+            key = (plan.world * plan.node_rows, width, X.device)
+            if getattr(self, "_gather_key", None) != key:
+                self._gather_bufs = [torch.empty(key[:2], dtype=torch.float32, device=X.device) for _ in range(2)]
+                self._gather_key = key
+            bufs = self._gather_bufs
+        ops.tower_stage(d, ptrs, n, -1, rows, ws, t_float=t, X_one_hot=X, Y32=Y32, layer_dst=bufs[0])
+        for l in range(d.num_layers):
+            src = gather(plan, bufs[l & 1], group) if need_gather else None
+            dst = bufs[(l + 1) & 1] if need_gather and l + 1 < d.num_layers else None
+            ops.tower_stage(d, ptrs, n, l, rows, ws, adj=A_t, layer_src=src, layer_dst=dst)
+        ops.tower_stage(d, ptrs, n, d.num_layers, rows, ws, out=out)
+        return out
+
+
 class GNNTower(_TowerBase):
     """model/gnn.py:72-176.  Same constructor and forward(t_float, X_t_one_hot, Y_real, A_t)."""
     _layers_attr = "gnn_layers"

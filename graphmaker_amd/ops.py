@@ -136,6 +136,16 @@ def tower_forward(dims, param_ptrs, n, t_float, X_one_hot, Y32, adj, workspace, 
     return (out, hcat) if want_hcat else out
 
 
+def tower_stage(dims, param_ptrs, n, stage, rows, workspace, *, t_float=None, X_one_hot=None, Y32=None, adj=None,
+                layer_src=None, layer_dst=None, out=None):
+    """One row-sharded stage of a tower (gm_tower_stage): -1 input projections, 0..L-1 layers, L output MLP."""
+    rowptr = adj.rowptr if adj is not None else None
+    colidx = adj.colidx if adj is not None else None
+    L.call("gm_tower_stage", C.byref(dims), param_ptrs, I64(n), I32(stage), I64(rows[0]), I64(rows[1]), ptr(t_float),
+           ptr(X_one_hot), ptr(Y32), ptr(rowptr), ptr(colidx), ptr(layer_src), ptr(layer_dst), ptr(out), ptr(workspace),
+           C.c_size_t(workspace.numel()), stream_ptr())
+
+
 def hadamard_gather(h, src, dst):
     require(h, torch.float32, "h")
     require(src, torch.int64, "src")

@@ -66,16 +66,28 @@ def all_gather_node_rows(plan, full, group=None):
     return full
 
 
+_scratch = {}
+
+
+def _persistent(name, shape, dtype, device):
+    """Buffers a collective touches are kept for the life of the process (the collective's stream holds references;
+    re-allocating them every step makes the caching allocator grow and stall)."""
+    key = (name, tuple(shape), dtype, device)
+    if key not in _scratch:
+        _scratch[key] = torch.zeros(shape, dtype=dtype, device=device)
+    return _scratch[key]
+
+
 def gather_upper_rows(plan, upper, group=None):
     """`upper` is the (n, wpr) int32 upper-triangle bitmap whose rows pair_chunks(rank) were written on this rank.
     After the call every rank holds every row.  Pack (2a rows) -> one all-gather -> unpack."""
     a, w = plan.chunk_rows, plan.world
     wpr = upper.shape[1]
-    send = torch.zeros((2 * a, wpr), dtype=upper.dtype, device=upper.device)
+    send = _persistent("send", (2 * a, wpr), upper.dtype, upper.device)   # rows beyond a short chunk stay zero
     for k, (b, e) in enumerate(plan.pair_chunks()):
         if e > b:
             send[k * a:k * a + (e - b)] = upper[b:e]
-    recv = torch.empty((w * 2 * a, wpr), dtype=upper.dtype, device=upper.device)
+    recv = _persistent("recv", (w * 2 * a, wpr), upper.dtype, upper.device)
     dist.all_gather_into_tensor(recv, send, group=group)
     recv = recv.view(w, 2 * a, wpr)
     for r in range(w):

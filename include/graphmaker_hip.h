@@ -98,6 +98,20 @@ int gm_tower_forward(const gm_tower_dims* dims, const float* const* params, int6
                      float* out, float* hcat_out, int64_t out_row_begin, int64_t out_row_end, void* workspace,
                      size_t workspace_bytes, gm_stream_t stream);
 
+/* One stage of a tower for node rows [row_begin,row_end) -- the unit of the multi-GPU decomposition, in which every
+ * stage is row-sharded and only the aggregation input crosses GPUs (same workspace for all stages of one forward):
+ *   stage -1        : input projections mlp_in_t / mlp_in_X / emb_Y (model/gnn.py:153-155)      needs t_float, X_one_hot, Y
+ *   stage l in [0,L): GNNLayer / MLPLayer l (model/gnn.py:40-70, :369-394)                        needs rowptr/colidx (GNN)
+ *   stage L         : mlp_out (model/gnn.py:165-176) -> rows of `out`
+ * layer_src: (n, hidden_X+hidden_Y) matrix [h_X^l | h_Y^l] of ALL nodes that stage l aggregates from (the all-gathered
+ *            buffer); NULL = read the tower's own hidden state (valid when this process computed every row).
+ * layer_dst: optional (n, hidden_X+hidden_Y) buffer; rows [row_begin,row_end) receive [h_X | h_Y] as written by this
+ *            stage (stage -1 -> h^0, stage l -> h^(l+1)): the send side of the all-gather. */
+int gm_tower_stage(const gm_tower_dims* dims, const float* const* params, int64_t n, int stage, int64_t row_begin,
+                   int64_t row_end, const float* t_float, const float* X_one_hot, const int32_t* Y,
+                   const int32_t* rowptr, const int32_t* colidx, const float* layer_src, float* layer_dst, float* out,
+                   void* workspace, size_t workspace_bytes, gm_stream_t stream);
+
 /* z[b] = h[src[b]] * h[dst[b]] for an explicit pair list: LinkPredictor.forward on a caller-chosen batch
  * (model/gnn.py:246); followed by two gm_linear calls it gives the (B,2) logits of model/gnn.py:248. */
 int gm_hadamard_gather(int64_t B, int64_t d, const int64_t* src, const int64_t* dst, const float* h, int64_t ldh,

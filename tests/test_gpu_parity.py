@@ -367,10 +367,23 @@ def test_rank_shards_reproduce_single_gpu_step(dev, world):
     up = torch.zeros_like(up_full)
     lg = torch.full_like(lg_full, float("nan"))
     xs = torch.full_like(xs_full, 255)
-    for r in range(world):
-        plan = ShardPlan.make(N, world, r)
-        enc._run(t_float, X_oh, Y32, A_t, rows=plan.node_range(), out=h)
-        pred_X._run(t_float, X_oh, Y32, A_t, rows=plan.node_range(), out=lg)
+    plans = [ShardPlan.make(N, world, r) for r in range(world)]
+
+    def staged(tower, out):
+        # every stage is run for each rank's rows in turn; the shared buffers play the part of the all-gathers
+        d, ptrs, ws = tower._dims, tower._param_ptrs(), tower._workspace(N, dev)
+        bufs = [torch.full((N, d.hidden_X + d.hidden_Y), float("nan"), device=dev) for _ in range(2)]
+        for pl in plans:
+            ops.tower_stage(d, ptrs, N, -1, pl.node_range(), ws, t_float=t_float, X_one_hot=X_oh, Y32=Y32, layer_dst=bufs[0])
+        for l in range(d.num_layers):
+            dst = bufs[(l + 1) & 1] if l + 1 < d.num_layers else None
+            for pl in plans:
+                ops.tower_stage(d, ptrs, N, l, pl.node_range(), ws, adj=A_t, layer_src=bufs[l & 1], layer_dst=dst)
+        for pl in plans:
+            ops.tower_stage(d, ptrs, N, d.num_layers, pl.node_range(), ws, out=out)
+
+    staged(enc, h)
+    staged(pred_X, lg)
     assert torch.equal(h, h_full) and torch.equal(lg, lg_full)
     for r in range(world):
         plan = ShardPlan.make(N, world, r)
