@@ -639,10 +639,15 @@ static void e_step(int64_t n, int64_t F, const gmo_tower_dims* dE, const float* 
 void gmo_sample_sync(int T, int64_t n, int64_t F, int C, const float* X_marginal, const float* Y_marginal,
                      const float* E_marginal, const gmo_tower_dims* dX, const float* const* pX,
                      const gmo_tower_dims* dE, const float* const* pE, const float* const* pPair,
-                     uint64_t seed, int as_reference, uint8_t* x, int32_t* y, uint32_t* bits, int64_t wpr) {
+                     uint64_t seed, int as_reference, uint8_t* x, int32_t* y, uint32_t* bits, int64_t wpr,
+                     const float* sched) {
     float* betas = (float*)malloc(sizeof(float) * (size_t)(T + 1) * 3);
     float *alphas = betas + (T + 1), *abars = betas + 2 * (T + 1);
     gmo_noise_schedule(T, betas, alphas, abars);
+    if (sched) { /* caller-supplied [alphas | alpha_bars]: the product's tables come from torch's log/exp */
+        memcpy(alphas, sched, sizeof(float) * (size_t)(T + 1));
+        memcpy(abars, sched + (T + 1), sizeof(float) * (size_t)(T + 1));
+    }
     gmo_prior_Y(n, C, Y_marginal, NULL, seed, y);
     gmo_prior_E(n, wpr, E_marginal[0], E_marginal[1], NULL, seed, bits);
     gmo_prior_X(n, F, X_marginal, NULL, seed, x);
@@ -679,13 +684,21 @@ void gmo_sample_async(int T_X, int T_E, int64_t n, int64_t F, int C, const float
                       const float* Y_marginal, const float* E_marginal, const gmo_tower_dims* dX,
                       const float* const* pX, const gmo_tower_dims* dE, const float* const* pE,
                       const float* const* pPair, uint64_t seed, int as_reference, uint8_t* x, int32_t* y,
-                      uint32_t* bits, int64_t wpr) {
+                      uint32_t* bits, int64_t wpr, const float* schedX, const float* schedE) {
     int Tm = T_X > T_E ? T_X : T_E;
     float* sx = (float*)malloc(sizeof(float) * (size_t)(Tm + 1) * 6);
     float *aX = sx + (Tm + 1), *abX = sx + 2 * (Tm + 1);
     float *bE = sx + 3 * (Tm + 1), *aE = sx + 4 * (Tm + 1), *abE = sx + 5 * (Tm + 1);
     gmo_noise_schedule(T_X, sx, aX, abX);                               /* diffusion.py:950 */
     gmo_noise_schedule(T_E, bE, aE, abE);                               /* :951 */
+    if (schedX) {
+        memcpy(aX, schedX, sizeof(float) * (size_t)(T_X + 1));
+        memcpy(abX, schedX + (T_X + 1), sizeof(float) * (size_t)(T_X + 1));
+    }
+    if (schedE) {
+        memcpy(aE, schedE, sizeof(float) * (size_t)(T_E + 1));
+        memcpy(abE, schedE + (T_E + 1), sizeof(float) * (size_t)(T_E + 1));
+    }
     gmo_prior_Y(n, C, Y_marginal, NULL, seed, y);                       /* :1319-1321 */
     gmo_prior_X(n, F, X_marginal, NULL, seed, x);                       /* :1325-1327 */
 

@@ -136,12 +136,13 @@ void gmo_onehot_from_x(int64_t n, int64_t F, const uint8_t* x, float* oh);
 void gmo_sample_sync(int T, int64_t n, int64_t F, int C, const float* X_marginal, const float* Y_marginal,
                      const float* E_marginal, const gmo_tower_dims* dX, const float* const* pX,
                      const gmo_tower_dims* dE, const float* const* pE, const float* const* pPair,
-                     uint64_t seed, int as_reference, uint8_t* x, int32_t* y, uint32_t* bits, int64_t wpr);
+                     uint64_t seed, int as_reference, uint8_t* x, int32_t* y, uint32_t* bits, int64_t wpr,
+                     const float* sched /* optional [alphas | alpha_bars], T+1 each */);
 void gmo_sample_async(int T_X, int T_E, int64_t n, int64_t F, int C, const float* X_marginal,
                       const float* Y_marginal, const float* E_marginal, const gmo_tower_dims* dX,
                       const float* const* pX, const gmo_tower_dims* dE, const float* const* pE,
                       const float* const* pPair, uint64_t seed, int as_reference, uint8_t* x, int32_t* y,
-                      uint32_t* bits, int64_t wpr);
+                      uint32_t* bits, int64_t wpr, const float* schedX, const float* schedE);
 
 #ifdef __cplusplus
 }

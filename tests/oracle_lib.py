@@ -353,7 +353,7 @@ def onehot_from_x(x):
     return oh
 
 
-def sample_sync(T, n, X_marginal, Y_marginal, E_marginal, towerX, towerE, pair, seed, as_reference=False):
+def sample_sync(T, n, X_marginal, Y_marginal, E_marginal, towerX, towerE, pair, seed, as_reference=False, sched=None):
     Xm, Ym, Em = f32(X_marginal), f32(Y_marginal), f32(E_marginal)
     F = Xm.shape[0]
     wpr = words_per_row(n)
@@ -363,12 +363,19 @@ def sample_sync(T, n, X_marginal, Y_marginal, E_marginal, towerX, towerE, pair, 
     lib().gmo_sample_sync(C.c_int(T), C.c_int64(n), C.c_int64(F), C.c_int(len(Ym)), _p(Xm), _p(Ym), _p(Em),
                           C.byref(towerX.dims), towerX._ptrs, C.byref(towerE.dims), towerE._ptrs,
                           pair._ptrs, C.c_uint64(seed), C.c_int(int(as_reference)), _p(x), _p(y), _p(bits),
-                          C.c_int64(wpr))
+                          C.c_int64(wpr), _p(_sched(sched)))
     return x, y, bits
 
 
+def _sched(s):
+    """(alphas, alpha_bars) -> one contiguous float32 array, or None."""
+    if s is None:
+        return None
+    return np.ascontiguousarray(np.concatenate([f32(s[0]), f32(s[1])]), np.float32)
+
+
 def sample_async(T_X, T_E, n, X_marginal, Y_marginal, E_marginal, towerX, towerE, pair, seed,
-                 as_reference=False):
+                 as_reference=False, schedX=None, schedE=None):
     Xm, Ym, Em = f32(X_marginal), f32(Y_marginal), f32(E_marginal)
     F = Xm.shape[0]
     wpr = words_per_row(n)
@@ -378,5 +385,5 @@ def sample_async(T_X, T_E, n, X_marginal, Y_marginal, E_marginal, towerX, towerE
     lib().gmo_sample_async(C.c_int(T_X), C.c_int(T_E), C.c_int64(n), C.c_int64(F), C.c_int(len(Ym)), _p(Xm),
                            _p(Ym), _p(Em), C.byref(towerX.dims), towerX._ptrs, C.byref(towerE.dims),
                            towerE._ptrs, pair._ptrs, C.c_uint64(seed), C.c_int(int(as_reference)), _p(x),
-                           _p(y), _p(bits), C.c_int64(wpr))
+                           _p(y), _p(bits), C.c_int64(wpr), _p(_sched(schedX)), _p(_sched(schedE)))
     return x, y, bits

@@ -396,7 +396,7 @@ def test_rank_shards_reproduce_single_gpu_step(dev, world):
     assert torch.equal(xs, xs_full)
 
 
-@pytest.mark.parametrize("n,F,ht", [(2708, 1433, 32), (13752, 767, 16)])
+@pytest.mark.parametrize("n,F,ht", [(2708, 1433, 32), (7650, 745, 16), (13752, 767, 16)])
 def test_full_size_step_properties_and_oracle_bands(dev, n, F, ht):
     """BASELINE.json sizes (Cora, amazon_computer): one whole Sync step at reference hidden sizes.  The oracle checks
     bands of pair-matrix rows and the tower outputs of a node sample bit for bit; the rest is covered by
@@ -467,3 +467,90 @@ def test_full_size_step_properties_and_oracle_bands(dev, n, F, ht):
         rp, ci = orc.csr_from_bitmap(bits_host, n)
         check_float(h, towerE.forward(np.float32(1.0), oh.cpu().numpy(), Y32.cpu().numpy(), rp, ci), LOGIT_ATOL, "edge tower, full size")
         check_float(logits, towerX.forward(np.float32(1.0), oh.cpu().numpy(), Y32.cpu().numpy(), rp, ci), LOGIT_ATOL, "node tower, full size")
+
+
+def _cora_model(variant, dev, seed):
+    """BASELINE.json configs 0/1: Cora shape (N=2708, F=1433, C=7) with the hidden sizes of configs/cora/*.yaml and
+    reference-shaped random weights (pre-trained checkpoints are remote fetches)."""
+    import graphmaker_amd as gm
+    n, F, C = 2708, 1433, 7
+    rs = np.random.RandomState(seed)
+    p1 = rs.uniform(0.002, 0.02, size=F).astype(np.float32)
+    Xm = np.stack([1 - p1, p1], 1).astype(np.float32)
+    Ym = np.full(C, 1.0 / C, np.float32)
+    Em = np.array([1 - 1.44e-3, 1.44e-3], np.float32)
+    gE = dict(hidden_t=32, hidden_X=512, hidden_Y=64, hidden_E=128, num_gnn_layers=2, dropout=0.0)
+    torch.manual_seed(seed)
+    kw = dict(X_marginal=t_(Xm, dev), Y_marginal=t_(Ym, dev), E_marginal=t_(Em, dev), num_nodes=n, gnn_E_config=gE)
+    if variant == "Sync":
+        model = gm.ModelSync(T=3, gnn_X_config=dict(hidden_t=32, hidden_X=512, hidden_Y=64, num_gnn_layers=2, dropout=0.0), **kw)
+    else:
+        model = gm.ModelAsync(T_X=6, T_E=9, mlp_X_config=dict(hidden_t=32, hidden_X=512, hidden_Y=64, num_mlp_layers=2,
+                                                               dropout=0.0), **kw)
+    with torch.no_grad():   # keep the untrained heads in the sparse regime of a trained model
+        model.graph_encoder.pred_E.mlp_out[2].bias += torch.tensor([3.0, -3.0])
+        bx = model.graph_encoder.pred_X.mlp_out[2].bias
+        bx[0::2] += 2.0
+        bx[1::2] -= 2.0
+    return model.to(dev).eval(), (Xm, Ym, Em), n
+
+
+@pytest.mark.parametrize("variant", ["Sync", "Async"])
+def test_cora_size_whole_sample_bit_identical_to_oracle(dev, variant):
+    """A complete sample() (priors + all reverse steps) at Cora size: attributes, labels and adjacency must equal the
+    CPU oracle's trajectory on the same Philox key bit for bit."""
+    model, (Xm, Ym, Em), n = _cora_model(variant, dev, 5)
+    sdX = {k: v.detach().cpu().numpy() for k, v in model.graph_encoder.pred_X.state_dict().items()}
+    sdE = {k: v.detach().cpu().numpy() for k, v in model.graph_encoder.pred_E.state_dict().items()}
+    towerX = orc.Tower.from_state_dict(sdX, is_mlp=(variant == "Async"))
+    towerE = orc.Tower.from_state_dict(sdE, is_mlp=False, prefix="gnn_encoder.")
+    pair = orc.PairMLP(sdE["mlp_out.0.weight"], sdE["mlp_out.0.bias"], sdE["mlp_out.2.weight"], sdE["mlp_out.2.bias"])
+    seed = 2024
+    X, Y1h, el = model.sample(seed=seed, dense=False)
+    if variant == "Sync":
+        ns = model.noise_schedule
+        x, y, bits = orc.sample_sync(3, n, Xm, Ym, Em, towerX, towerE, pair, seed, sched=(ns.alphas_host, ns.alpha_bars_host))
+    else:
+        nx, ne = model.noise_schedule_X, model.noise_schedule_E
+        x, y, bits = orc.sample_async(6, 9, n, Xm, Ym, Em, towerX, towerE, pair, seed,
+                                      schedX=(nx.alphas_host, nx.alpha_bars_host), schedE=(ne.alphas_host, ne.alpha_bars_host))
+    np.testing.assert_array_equal(Y1h.argmax(1).cpu().numpy(), y)
+    np.testing.assert_array_equal(X[:, :, 1].T.cpu().numpy().astype(np.uint8), x)
+    ei, ej = orc.upper_edges_from_bitmap(bits, n)
+    np.testing.assert_array_equal(el.cpu().numpy(), np.stack([ei, ej]))
+    assert 0 < len(ei) < n * 200, "degenerate graph: the comparison would be vacuous"
+
+
+def test_sbm100k_structure_step_bands(dev):
+    """BASELINE.json config 4 scale (N = 100,000; 5e9 pairs): one pass of the pair kernel on a single GPU, checked
+    against the oracle on row bands; exercises 64-bit pair ranks, 1.2 M tiles and the 1.25 GB bitmaps."""
+    ops = _ops()
+    n = 100_000
+    g = torch.Generator(device="cpu").manual_seed(1)
+    h = (torch.randn(n, 128, generator=g) * 0.4).to(dev)
+    W1 = (torch.randn(128, 128, generator=g) / 11).to(dev)
+    b1 = (torch.randn(128, generator=g) * 0.1).to(dev)
+    W2 = (torch.randn(2, 128, generator=g) / 11).to(dev)
+    b2 = torch.tensor([4.0, -4.0], device=dev)
+    Em = np.array([1 - 4e-5, 4e-5], np.float32)              # mean degree 4
+    bits = ops.prior_E(n, float(Em[0]), float(Em[1]), dev, seed=3)
+    tab = orc.posterior_table_E(Em, 0.58304191, 0.84701216, 0.49384356)
+    up = ops.pair_score_sample(h, W1, b1, W2, b2, bits, tab, seed=9, step=2)
+    sym = ops.symmetrize_upper(up, n)
+    rowptr, colidx = ops.csr_from_bitmap(sym, n)
+    deg = (rowptr[1:] - rowptr[:-1])
+    assert int(rowptr[n]) % 2 == 0 and int(deg.max()) < n
+    # symmetry without a dense matrix: the CSR of the transpose equals the CSR (row list == sorted column list)
+    rows = torch.repeat_interleave(torch.arange(n, device=dev), deg.long())
+    order = torch.argsort(colidx.long() * n + rows)
+    assert torch.equal(rows[order].int(), colidx) and torch.equal(colidx[order].long(), rows)
+    pair = orc.PairMLP(W1.cpu().numpy(), b1.cpu().numpy(), W2.cpu().numpy(), b2.cpu().numpy())
+    h_np, bits_host, got = h.cpu().numpy(), bits_np(bits), bits_np(up)
+    nw = (n + 31) // 32
+    for r0, r1 in [(0, 1), (46341, 46342), (65535, 65537), (n - 65, n - 64), (n - 2, n)]:
+        want = orc.pair_score_sample(n, h_np, pair, bits_host, tab, seed=9, step=2, row_begin=r0, row_end=r1)
+        for i in range(r0, r1):
+            w0 = i >> 5
+            keep = np.uint32((0xFFFFFFFF << ((i & 31) + 1)) & 0xFFFFFFFF)
+            assert (got[i, w0] & keep) == want[i, w0]
+            np.testing.assert_array_equal(got[i, w0 + 1:nw], want[i, w0 + 1:nw])
