@@ -91,7 +91,21 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ h, int64_t 
 struct Frag {
     float4 w[4];
     float4 hi, ha, hb;
+    float z0[4], z1[4];   // h_i * h_j for the fragment's four k-steps, strip 0 / strip 1
 };
+
+// z for a fragment whose LDS reads have landed.  Done one half-iteration ahead of the MFMAs that consume it, so the
+// multiplies (and the VALU->MFMA operand wait states) run in the shadow of the previous block's last MFMAs.
+__device__ __forceinline__ void prep_frag(Frag& f) {
+    const float hiv[4] = {f.hi.x, f.hi.y, f.hi.z, f.hi.w};
+    const float hav[4] = {f.ha.x, f.ha.y, f.ha.z, f.ha.w};
+    const float hbv[4] = {f.hb.x, f.hb.y, f.hb.z, f.hb.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        f.z0[e] = hiv[e] * hav[e];
+        f.z1[e] = hiv[e] * hbv[e];
+    }
+}
 
 __device__ __forceinline__ void load_frag(Frag& f, const float* wrow, const float* hirow, const float* hjrow, int q) {
 #pragma unroll
@@ -103,13 +117,9 @@ __device__ __forceinline__ void load_frag(Frag& f, const float* wrow, const floa
 
 // 4 k-steps (k = 8q .. 8q+7) on both strips: 32 MFMAs
 __device__ __forceinline__ void mma_frag(floatx16 (&acc)[2][4], const Frag& f) {
-    const float hiv[4] = {f.hi.x, f.hi.y, f.hi.z, f.hi.w};
-    const float hav[4] = {f.ha.x, f.ha.y, f.ha.z, f.ha.w};
-    const float hbv[4] = {f.hb.x, f.hb.y, f.hb.z, f.hb.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const float z0 = hiv[e] * hav[e];
-        const float z1 = hiv[e] * hbv[e];
+        const float z0 = f.z0[e], z1 = f.z1[e];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const float wv_ = e == 0 ? f.w[mt].x : e == 1 ? f.w[mt].y : e == 2 ? f.w[mt].z : f.w[mt].w;
@@ -220,6 +230,7 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
                     st_init += m1 - m0;
 #endif
                     load_frag(f0, wrow, hirow, hjrow, 0);
+                    prep_frag(f0);
 #pragma unroll 1
                     for (int q = 0; q < HE / 8; q += 2) {
 #ifdef GM_PAIR_NO_LDS   // exploration only
@@ -229,11 +240,15 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
                         __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMAs it overlaps
                         mma_frag(acc, f0);
                         __builtin_amdgcn_sched_barrier(0);
+                        prep_frag(f1);
+                        __builtin_amdgcn_sched_barrier(0);
 #ifndef GM_PAIR_NO_LDS
                         load_frag(f0, wrow, hirow, hjrow, (q + 2) & (HE / 8 - 1));
 #endif
                         __builtin_amdgcn_sched_barrier(0);
                         mma_frag(acc, f1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        prep_frag(f0);
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #ifdef GM_PAIR_STAMP
