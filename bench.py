@@ -34,6 +34,7 @@ SMALL = dict(name="cora_shape", N=2708, F=1433, C=7, T=3, density=1.44e-3,
 
 FLOP_PER_PAIR = 2 * 128 * 128 + 2 * 128 * 2 + 128      # 33,408
 F32_MFMA_PEAK_TFLOPS = 157.3                            # MI355X_MICROARCH.md: dense f32 matrix peak
+HBM_PEAK_GBS = 8000.0                                   # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
 def build_model(wl, dev):
@@ -102,6 +103,48 @@ def cpu_baseline(wl, model, state, budget_rows=768, threads=None):
                       "pair count; encoder hoisted once per step (the reference re-runs it per 32768-pair batch)"}
 
 
+def _time_ms(fn, reps=20, warm=3):
+    """Average duration of fn() in ms from events on torch's current stream (the stream every C-ABI call is given)."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def secondary_rooflines(wl, model, bits, dev):
+    """The other two kernels north_star names, measured alone (outside the timed region) at this workload's shapes:
+    the d=576 mean-aggregation SpMM against HBM (compulsory bytes) and the largest tower GEMM against the
+    f32 MFMA peak."""
+    from graphmaker_amd import ops
+    n = wl["N"]
+    adj = ops.adjacency_from_bitmap(bits, n)
+    nnz = adj.nnz
+    d = wl["gnn_E"]["hidden_X"] + wl["gnn_E"]["hidden_Y"]
+    H = torch.randn(n, d, device=dev)
+    t_spmm = _time_ms(lambda: ops.spmm_mean(adj, H))
+    compulsory = 4 * (n + 1) + 4 * nnz + 2 * 4 * n * d
+    gather = 4 * nnz * d + 4 * n * d + 4 * nnz + 4 * (n + 1)
+    Hc = 3 * d + wl["gnn_E"]["hidden_t"]
+    A = torch.randn(n, Hc, device=dev)
+    W = torch.randn(Hc, Hc, device=dev) * 0.02
+    b = torch.zeros(Hc, device=dev)
+    t_gemm = _time_ms(lambda: ops.linear(A, W, b, relu=True), reps=10)
+    tf = 2.0 * n * Hc * Hc / (t_gemm * 1e-3) / 1e12
+    return [
+        {"kernel": "gm::k_spmm_mean", "bound": "hbm", "achieved": compulsory / (t_spmm * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+         "unit": "GB/s", "frac": compulsory / (t_spmm * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+         "launch_ms": t_spmm, "bytes_per_launch": compulsory, "gather_GBps": gather / (t_spmm * 1e-3) / 1e9,
+         "shape": f"N={n} nnz={nnz} d={d}"},
+        {"kernel": "gm::k_linear", "bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+         "frac": tf / F32_MFMA_PEAK_TFLOPS, "traffic": None, "launch_ms": t_gemm, "shape": f"M={n} N={Hc} K={Hc} +bias+ReLU"},
+    ]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,6 +152,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="amazon_computer", choices=["amazon_computer", "cora_shape"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the stand-alone SpMM/GEMM timings and the full-sample run (profiling passes use this)")
     ap.add_argument("--cpu-rows", type=int, default=768)
     ap.add_argument("--force-plan", action="store_true",
                     help="run the sharded code path (ShardPlan + RCCL all-gathers) even with one rank: a rehearsal of N>1")
@@ -199,6 +244,12 @@ def main():
                          "traffic": traffic, "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch_rank0": pairs_here,
                          "launch_ms": pair_ms},
         }
+        if world == 1 and not args.no_extras:
+            res["roofline_secondary"] = secondary_rooflines(wl, model, bits, dev)
+            t0 = time.perf_counter()
+            model.sample(seed=7, dense=False)
+            torch.cuda.synchronize()
+            res["full_sample_ms"] = (time.perf_counter() - t0) * 1e3     # priors + all T steps, one GPU, free-running
         if not args.no_cpu_baseline and world == 1:
             try:
                 res["cpu_baseline"] = cpu_baseline(wl, model, (x, oh, Y32, bits), budget_rows=args.cpu_rows,
