@@ -1,0 +1,302 @@
+"""The tape of the training step (reference: log_p_t, model/diffusion.py:606-654, :1035-1094, driven by
+train_sync.py:94-120 / train_async.py).  torch.autograd only records the operator graph; every forward and every
+gradient below is one or a few calls into libgraphmaker_hip.so (gm_train.hip, gm_gemm.hip, gm_nodeops.hip).  All
+reductions run in a fixed order, so a step is reproducible run to run.
+
+Operators (each a torch.autograd.Function over contiguous float32 device tensors):
+    linear(x, W, b, relu)            nn.Linear (+ReLU)                         model/gnn.py:116-126,138-142,226-230
+    update_block(x, W, b, g, beta)   Linear -> ReLU -> LayerNorm               model/gnn.py:27-38
+    spmm_mean(adj, H)                A @ H with A = D^-1 A                     model/gnn.py:60-61
+    embedding(weight, idx)           nn.Embedding                              model/gnn.py:155
+    hadamard_gather(h, src, dst)     h[src] * h[dst]                           model/gnn.py:246
+    softmax_ce2(logits, target)      F.cross_entropy, 2 classes, mean          model/diffusion.py:139,513
+    dropout(x, p, seed, call)        nn.Dropout in training mode               model/gnn.py:31,37
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+from ._lib import F32, I32, I64, U32, U64, ptr, require, stream_ptr
+
+_scratch_bufs = {}
+
+
+def _scratch(nbytes, device, slot=0):
+    """Device scratch for split-K / block partials.  One buffer per (device, slot), grown on demand; kernels that use
+    it run back to back on the current stream, so sharing is safe."""
+    key = (device, slot)
+    buf = _scratch_bufs.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _scratch_bufs[key] = buf
+    return buf
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def C_void(t, offset_elems):
+    """Pointer to element `offset_elems` of a float32 tensor."""
+    return ctypes.c_void_p(t.data_ptr() + 4 * offset_elems)
+
+
+def gemm(a_red, b_red, M, N, K, A, lda, B, ldb, *, bias=None, mask=None, relu=False, out=None):
+    """gm_gemm: C[m][n] = act(sum_k a(m,k) b(n,k) + bias[n]) (zero where mask <= 0)."""
+    dev = A.device
+    C_ = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=dev)
+    need = L.load().gm_gemm_workspace_bytes(I64(M), I64(N), I64(K))
+    ws = _scratch(need, dev) if need else None
+    L.call("gm_gemm", I32(int(a_red)), I32(int(b_red)), I64(M), I64(N), I64(K), ptr(A), I64(lda), ptr(B), I64(ldb), ptr(bias),
+           ptr(mask), I64(N if mask is not None else 0), I32(int(relu)), ptr(C_), I64(N), ptr(ws), I64(ws.numel() if ws is not None else 0),
+           stream_ptr())
+    return C_
+
+
+def colsum(X):
+    M, N = X.shape
+    out = torch.empty(N, dtype=torch.float32, device=X.device)
+    need = L.load().gm_colsum_workspace_bytes(I64(M), I64(N))
+    ws = _scratch(need, X.device)
+    L.call("gm_colsum", I64(M), I64(N), ptr(X), I64(N), ptr(out), ptr(ws), I64(ws.numel()), stream_ptr())
+    return out
+
+
+def _linear_backward(x, W, g, needs):
+    """(dx, dW, db) of y = x W^T + b for the gradient g of y (already masked by any ReLU)."""
+    M, K = x.shape
+    N = W.shape[0]
+    dx = gemm(False, True, M, K, N, g, N, W, K) if needs[0] else None             # dY W
+    dW = gemm(True, True, N, K, M, g, N, x, K) if needs[1] else None              # dY^T X
+    db = colsum(g) if needs[2] else None
+    return dx, dW, db
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, b, relu):
+        x, W = _c(x), _c(W)
+        require(x, torch.float32, "x")
+        require(W, torch.float32, "W")
+        M, K = x.shape
+        N = W.shape[0]
+        if W.shape[1] != K:
+            raise ValueError(f"linear: x is {tuple(x.shape)}, W is {tuple(W.shape)}")
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        L.call("gm_linear", I64(M), I64(N), I64(K), ptr(x), I64(K), ptr(W), I64(K), ptr(b), ptr(y), I64(N), I32(int(relu)),
+               stream_ptr())
+        ctx.relu = relu
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, W, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W, y = ctx.saved_tensors
+        g = _c(g)
+        if ctx.relu:
+            gm = torch.empty_like(g)
+            L.call("gm_relu_bwd", I64(g.numel()), ptr(g), ptr(y), ptr(gm), stream_ptr())
+            g = gm
+        needs = (ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
+        dx, dW, db = _linear_backward(x, W, g, needs)
+        return dx, dW, db, None
+
+
+class _UpdateBlock(torch.autograd.Function):
+    """Linear -> ReLU -> LayerNorm of GNNLayer / MLPLayer (model/gnn.py:27-38)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, gamma, beta, eps):
+        x, W = _c(x), _c(W)
+        require(x, torch.float32, "x")
+        M, K = x.shape
+        N = W.shape[0]
+        dev = x.device
+        a = torch.empty((M, N), dtype=torch.float32, device=dev)
+        L.call("gm_linear", I64(M), I64(N), I64(K), ptr(x), I64(K), ptr(W), I64(K), ptr(b), ptr(a), I64(N), I32(1), stream_ptr())
+        y = torch.empty_like(a)
+        mean = torch.empty(M, dtype=torch.float32, device=dev)
+        rstd = torch.empty(M, dtype=torch.float32, device=dev)
+        L.call("gm_layernorm_fwd", I64(M), I64(N), ptr(a), I64(N), ptr(gamma), ptr(beta), F32(eps), ptr(y), I64(N), ptr(mean),
+               ptr(rstd), stream_ptr())
+        ctx.save_for_backward(x, W, a, mean, rstd, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W, a, mean, rstd, gamma = ctx.saved_tensors
+        g = _c(g)
+        M, N = a.shape
+        dev = a.device
+        da = torch.empty_like(a)
+        dgb = torch.empty((2, N), dtype=torch.float32, device=dev)
+        need = L.load().gm_layernorm_bwd_workspace_bytes(I64(M), I64(N))
+        ws = _scratch(need, dev)
+        L.call("gm_layernorm_bwd", I64(M), I64(N), ptr(g), I64(N), ptr(a), I64(N), ptr(mean), ptr(rstd), ptr(gamma), I32(1),
+               ptr(da), I64(N), ptr(dgb), C_void(dgb, N), ptr(ws), I64(ws.numel()), stream_ptr())
+        dx, dW, db = _linear_backward(x, W, da, (ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]))
+        return dx, dW, db, dgb[0], dgb[1], None
+
+
+class _SpmmMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, H, adj):
+        H = _c(H)
+        require(H, torch.float32, "H")
+        n, d = H.shape
+        out = torch.empty_like(H)
+        L.call("gm_spmm_mean", I64(n), ptr(adj.rowptr), ptr(adj.colidx), ptr(H), I64(d), I64(d), ptr(out), I64(d), stream_ptr())
+        ctx.adj = adj
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        n, d = g.shape
+        adj = ctx.adj
+        out = torch.empty_like(g)
+        L.call("gm_spmm_mean_bwd", I64(n), ptr(adj.rowptr), ptr(adj.colidx), ptr(g), I64(d), I64(d), ptr(out), I64(d),
+               stream_ptr())
+        return out, None
+
+
+class _Embedding(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weight, idx32):
+        weight = _c(weight)
+        require(weight, torch.float32, "emb.weight")
+        require(idx32, torch.int32, "idx")
+        n = idx32.numel()
+        Cn, w = weight.shape
+        out = torch.empty((n, w), dtype=torch.float32, device=weight.device)
+        L.call("gm_embedding_fwd", I64(n), I32(Cn), I32(w), ptr(idx32), ptr(weight), I64(w), ptr(out), I64(w), stream_ptr())
+        ctx.save_for_backward(idx32)
+        ctx.shape = (Cn, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx32,) = ctx.saved_tensors
+        g = _c(g)
+        Cn, w = ctx.shape
+        dW = torch.empty((Cn, w), dtype=torch.float32, device=g.device)
+        L.call("gm_embedding_bwd", I64(idx32.numel()), I32(Cn), I32(w), ptr(idx32), ptr(g), I64(w), ptr(dW), I64(w), stream_ptr())
+        return dW, None
+
+
+class _HadamardGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, src, dst):
+        h = _c(h)
+        require(h, torch.float32, "h")
+        src, dst = _c(src), _c(dst)
+        require(src, torch.int64, "src")
+        require(dst, torch.int64, "dst")
+        B, d = src.numel(), h.shape[1]
+        out = torch.empty((B, d), dtype=torch.float32, device=h.device)
+        L.call("gm_hadamard_gather", I64(B), I64(d), ptr(src), ptr(dst), ptr(h), I64(d), ptr(out), I64(d), stream_ptr())
+        ctx.save_for_backward(h, src, dst)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        h, src, dst = ctx.saved_tensors
+        g = _c(g)
+        n, d = h.shape
+        B = src.numel()
+        # group the 2B (pair, role) entries by node: index plumbing (a stable sort of the ids), then one kernel
+        keys = torch.cat([src, dst])
+        order = torch.argsort(keys, stable=True)
+        counts = torch.bincount(keys, minlength=n)
+        segptr = torch.zeros(n + 1, dtype=torch.int64, device=h.device)
+        segptr[1:] = torch.cumsum(counts, 0)
+        dh = torch.empty_like(h)
+        L.call("gm_hadamard_gather_bwd", I64(n), I64(B), I64(d), ptr(src), ptr(dst), ptr(segptr), ptr(order), ptr(h), I64(d),
+               ptr(g), I64(d), ptr(dh), I64(d), stream_ptr())
+        return dh, None, None
+
+
+class _SoftmaxCE2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target_u8):
+        logits = _c(logits)
+        require(logits, torch.float32, "logits")
+        require(target_u8, torch.uint8, "target")
+        total = target_u8.numel()
+        if logits.numel() != 2 * total:
+            raise ValueError(f"softmax_ce2: {logits.numel()} logits for {total} targets")
+        dev = logits.device
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        dl = torch.empty_like(logits) if ctx.needs_input_grad[0] else None
+        ws = _scratch(L.load().gm_softmax_ce2_workspace_bytes(), dev, slot=1)
+        L.call("gm_softmax_ce2", I64(total), ptr(logits), ptr(target_u8), ptr(loss), ptr(dl), ptr(ws), I64(ws.numel()),
+               stream_ptr())
+        ctx.save_for_backward(dl)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed, call):
+        x = _c(x)
+        out = torch.empty_like(x)
+        L.call("gm_dropout", I64(x.numel()), ptr(x), F32(p), U64(seed), U32(call), ptr(out), stream_ptr())
+        ctx.args = (p, seed, call)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        p, seed, call = ctx.args
+        out = torch.empty_like(g)
+        L.call("gm_dropout", I64(g.numel()), ptr(g), F32(p), U64(seed), U32(call), ptr(out), stream_ptr())
+        return out, None, None, None
+
+
+def linear(x, W, b=None, relu=False):
+    return _Linear.apply(x, W, b, relu)
+
+
+def update_block(x, W, b, gamma, beta, eps=1e-5):
+    return _UpdateBlock.apply(x, W, b, gamma, beta, eps)
+
+
+def spmm_mean(adj, H):
+    return _SpmmMean.apply(H, adj)
+
+
+def embedding(weight, idx32):
+    return _Embedding.apply(weight, idx32)
+
+
+def hadamard_gather(h, src, dst):
+    return _HadamardGather.apply(h, src, dst)
+
+
+def softmax_ce2(logits, target_u8):
+    return _SoftmaxCE2.apply(logits, target_u8)
+
+
+class DropoutState:
+    """Seed and call counter of the dropout masks of one model (a fresh mask per application, reproducible per seed)."""
+
+    def __init__(self, seed=0):
+        self.seed, self.calls = int(seed) & 0xFFFFFFFFFFFFFFFF, 0
+
+    def next(self):
+        self.calls = (self.calls + 1) & 0xFFFFFFFF
+        return self.seed, self.calls
+
+
+def dropout(x, p, state):
+    if p <= 0.0:
+        return x
+    seed, call = state.next()
+    return _Dropout.apply(x, float(p), seed, call)

@@ -1,0 +1,645 @@
+// gm_train.hip -- kernels of the training step log_p_t (model/diffusion.py:606-654, :1035-1094; train_sync.py:94-120):
+// the backward halves of the denoiser's operators.  torch.autograd is only the tape (graphmaker_amd/autograd.py);
+// every gradient is computed here.
+//
+//   gm_gemm              C[m][n] = sum_k a(m,k) b(n,k) with either operand stored reduction-major, deterministic split-K:
+//                          dX = dY W          (a = dY rows,      b = W  reduction-major)     nn.Linear backward
+//                          dW = dY^T X        (a = dY red-major, b = X  reduction-major)
+//   gm_colsum            db = column sums of dY
+//   gm_layernorm_fwd/bwd nn.LayerNorm (model/gnn.py:30,36) out of place with saved mean / rstd; the backward also applies
+//                        the mask of the ReLU in front of it and returns d gamma / d beta
+//   gm_spmm_mean_bwd     (D^-1 A)^T G : out[j] = sum_{i in N(j)} G[i] / deg(i)   (A symmetric, model/gnn.py:60-61)
+//   gm_embedding_bwd     d emb_Y.weight (model/gnn.py:155)
+//   gm_hadamard_gather_bwd   d h of z = h[src] * h[dst] (model/gnn.py:246) by node-grouped segments, no atomics
+//   gm_softmax_ce2       F.cross_entropy over 2 classes, mean reduction (LossX / LossE, model/diffusion.py:120-141,474-515)
+//
+// All reductions run in a fixed order (ascending k inside a split, splits / blocks summed in ascending order), so a
+// training step is reproducible run to run.  MFMA f32 (v_mfma_f32_32x32x2_f32) for the GEMMs; the rest is HBM-bound.
+#include "gm_common.h"
+
+namespace gm {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int TBM = 128, TBN = 128, TBK = 16;
+constexpr int TLDT = TBM + 4;
+
+// ---- operand staging: a 128 (outputs) x 16 (reduction) tile -> 8 registers per thread
+// RED = false: memory is [out][red] (reduction contiguous): thread -> out row tid/2, 8 reduction values
+// RED = true : memory is [red][out] (outputs contiguous):   thread -> reduction row tid/16, 8 consecutive outputs
+template <bool RED>
+__device__ __forceinline__ void stage_load(const float* __restrict__ P, int64_t ld, int64_t o0, int64_t O, int64_t k0,
+                                           int64_t kend, bool vec, int tid, float (&r)[8]) {
+    if (!RED) {
+        const int64_t o = o0 + (tid >> 1), kk = k0 + (tid & 1) * 8;
+        if (o >= O || kk >= kend) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) r[q] = 0.0f;
+            return;
+        }
+        const float* p = P + o * ld + kk;
+        if (vec && kk + 8 <= kend) {
+            const float4 v0 = *reinterpret_cast<const float4*>(p), v1 = *reinterpret_cast<const float4*>(p + 4);
+            r[0] = v0.x; r[1] = v0.y; r[2] = v0.z; r[3] = v0.w; r[4] = v1.x; r[5] = v1.y; r[6] = v1.z; r[7] = v1.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) r[q] = (kk + q < kend) ? p[q] : 0.0f;
+        }
+    } else {
+        const int64_t kk = k0 + (tid >> 4), o = o0 + (tid & 15) * 8;
+        if (kk >= kend || o >= O) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) r[q] = 0.0f;
+            return;
+        }
+        const float* p = P + kk * ld + o;
+        if (vec && o + 8 <= O) {
+            const float4 v0 = *reinterpret_cast<const float4*>(p), v1 = *reinterpret_cast<const float4*>(p + 4);
+            r[0] = v0.x; r[1] = v0.y; r[2] = v0.z; r[3] = v0.w; r[4] = v1.x; r[5] = v1.y; r[6] = v1.z; r[7] = v1.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) r[q] = (o + q < O) ? p[q] : 0.0f;
+        }
+    }
+}
+template <bool RED>
+__device__ __forceinline__ void stage_store(float* __restrict__ S, int tid, const float (&r)[8]) {
+    if (!RED) {
+        const int row = tid >> 1, kh = (tid & 1) * 8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) S[(kh + q) * TLDT + row] = r[q];
+    } else {
+        float* d = S + (tid >> 4) * TLDT + (tid & 15) * 8;
+        *reinterpret_cast<float4*>(d) = make_float4(r[0], r[1], r[2], r[3]);
+        *reinterpret_cast<float4*>(d + 4) = make_float4(r[4], r[5], r[6], r[7]);
+    }
+}
+
+// C tile epilogue shared by the direct and the split-K reduce path
+__device__ __forceinline__ float finish(float v, const float* bias, const float* mask, int64_t ldmask, int relu, int64_t m,
+                                        int64_t n) {
+    if (bias) v = v + bias[n];
+    if (mask && !(mask[m * ldmask + n] > 0.0f)) v = 0.0f;
+    if (relu && !(v > 0.0f)) v = 0.0f;
+    return v;
+}
+
+template <bool A_RED, bool B_RED>
+__global__ void __launch_bounds__(256, 2)
+k_gemm_g(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
+         const float* __restrict__ bias, const float* __restrict__ mask, int64_t ldmask, int relu, float* __restrict__ C,
+         int64_t ldc, int64_t kchunk, int64_t split_stride, int vecA, int vecB) {
+    __shared__ __attribute__((aligned(16))) float As[TBK * TLDT];
+    __shared__ __attribute__((aligned(16))) float Bs[TBK * TLDT];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int64_t m0 = (int64_t)blockIdx.y * TBM, n0 = (int64_t)blockIdx.x * TBN;
+    const int64_t kb = (int64_t)blockIdx.z * kchunk;
+    const int64_t ke = kb + kchunk < K ? kb + kchunk : K;
+    const bool partial = split_stride != 0;
+    float* Cz = C + (int64_t)blockIdx.z * split_stride;
+
+    float ra[8], rb[8];
+    stage_load<A_RED>(A, lda, m0, M, kb, ke, vecA != 0, tid, ra);
+    stage_load<B_RED>(B, ldb, n0, N, kb, ke, vecB != 0, tid, rb);
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    for (int64_t k0 = kb; k0 < ke; k0 += TBK) {
+        __syncthreads();
+        stage_store<A_RED>(As, tid, ra);
+        stage_store<B_RED>(Bs, tid, rb);
+        __syncthreads();
+        if (k0 + TBK < ke) {
+            stage_load<A_RED>(A, lda, m0, M, k0 + TBK, ke, vecA != 0, tid, ra);
+            stage_load<B_RED>(B, ldb, n0, N, k0 + TBK, ke, vecB != 0, tid, rb);
+        }
+#pragma unroll
+        for (int ks = 0; ks < TBK / 2; ++ks) {
+            const int krow = (2 * ks + half) * TLDT;
+            const float a0 = As[krow + wm * 64 + l31];
+            const float a1 = As[krow + wm * 64 + 32 + l31];
+            const float b0 = Bs[krow + wn * 64 + l31];
+            const float b1 = Bs[krow + wn * 64 + 32 + l31];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int64_t n = n0 + wn * 64 + b * 32 + l31;
+        if (n >= N) continue;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < M) {
+                    if (partial) Cz[m * N + n] = acc[a][b][r];
+                    else C[m * ldc + n] = finish(acc[a][b][r], bias, mask, ldmask, relu, m, n);
+                }
+            }
+        }
+    }
+}
+
+// C[m][n] = finish( sum_{s ascending} part[s][m][n] )
+__global__ void k_splitk_reduce(int S, int64_t M, int64_t N, const float* __restrict__ part, const float* __restrict__ bias,
+                                const float* __restrict__ mask, int64_t ldmask, int relu, float* __restrict__ C, int64_t ldc) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= M * N) return;
+    float acc = part[g];
+    for (int s = 1; s < S; ++s) acc = acc + part[(int64_t)s * M * N + g];
+    const int64_t m = g / N, n = g % N;
+    C[m * ldc + n] = finish(acc, bias, mask, ldmask, relu, m, n);
+}
+
+// ---- column sums: part[blk][n] = sum over the block's rows (ascending, 4 row lanes combined in order)
+constexpr int CS_ROWS = 64;   // rows per block
+__global__ void __launch_bounds__(256)
+k_colsum_partial(int64_t M, int64_t N, const float* __restrict__ X, int64_t ldx, float* __restrict__ part) {
+    __shared__ float red[4][64];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int64_t n = (int64_t)blockIdx.x * 64 + c;
+    const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS;
+    float acc = 0.0f;
+    if (n < N)
+        for (int64_t m = r0 + rl; m < r0 + CS_ROWS && m < M; m += 4) acc = acc + X[m * ldx + n];
+    red[rl][c] = acc;
+    __syncthreads();
+    if (rl == 0 && n < N) part[(int64_t)blockIdx.y * N + n] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+}
+
+// ---- LayerNorm forward with saved statistics (same arithmetic as k_layernorm in gm_nodeops.hip)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off);
+    return v;
+}
+__global__ void __launch_bounds__(256)
+k_layernorm_fwd(int64_t M, int64_t N, const float* __restrict__ X, int64_t ldx, const float* __restrict__ gamma,
+                const float* __restrict__ beta, float eps, float* __restrict__ Y, int64_t ldy, float* __restrict__ mean_out,
+                float* __restrict__ rstd_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float* x = X + m * ldx;
+    float s = 0.0f;
+    for (int64_t c = lane; c < N; c += 64) s = s + x[c];
+    const float mean = wave_sum(s) / (float)N;
+    float q = 0.0f;
+    for (int64_t c = lane; c < N; c += 64) {
+        float t = x[c] - mean;
+        q = q + t * t;
+    }
+    const float var = wave_sum(q) / (float)N;
+    const float rstd = 1.0f / __builtin_sqrtf(var + eps);
+    for (int64_t c = lane; c < N; c += 64) {
+        float t = (x[c] - mean) * rstd;
+        float g = t * gamma[c];
+        Y[m * ldy + c] = g + beta[c];
+    }
+    if (lane == 0) {
+        mean_out[m] = mean;
+        rstd_out[m] = rstd;
+    }
+}
+
+// backward: one wave per row, LN_ROWS rows per block; per-lane column partials of d gamma / d beta are combined over the
+// block's 4 waves in LDS and written as part[blk][0][c] (d gamma), part[blk][1][c] (d beta).  N <= 64*LN_MAXQ.
+constexpr int LN_ROWS = 32, LN_MAXQ = 16;
+__global__ void __launch_bounds__(256)
+k_layernorm_bwd(int64_t M, int64_t N, const float* __restrict__ dY, int64_t lddy, const float* __restrict__ X, int64_t ldx,
+                const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                int relu_mask, float* __restrict__ dX, int64_t lddx, float* __restrict__ part) {
+    extern __shared__ float red[];   // [4][2][N]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float dg[LN_MAXQ], db[LN_MAXQ];
+#pragma unroll
+    for (int q = 0; q < LN_MAXQ; ++q) dg[q] = db[q] = 0.0f;
+    const int64_t r0 = (int64_t)blockIdx.x * LN_ROWS;
+    for (int64_t m = r0 + wv; m < r0 + LN_ROWS && m < M; m += 4) {
+        const float mu = mean[m], rs = rstd[m];
+        const float* x = X + m * ldx;
+        const float* dy = dY + m * lddy;
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < LN_MAXQ; ++q) {
+            const int64_t c = lane + 64 * q;
+            if (c < N) {
+                const float xh = (x[c] - mu) * rs;
+                const float g = dy[c] * gamma[c];
+                s1 = s1 + g;
+                s2 = s2 + g * xh;
+                dg[q] = dg[q] + dy[c] * xh;
+                db[q] = db[q] + dy[c];
+            }
+        }
+        s1 = wave_sum(s1) / (float)N;
+        s2 = wave_sum(s2) / (float)N;
+#pragma unroll
+        for (int q = 0; q < LN_MAXQ; ++q) {
+            const int64_t c = lane + 64 * q;
+            if (c < N) {
+                const float xv = x[c];
+                const float xh = (xv - mu) * rs;
+                const float g = dy[c] * gamma[c];
+                float v = rs * ((g - s1) - xh * s2);
+                if (relu_mask && !(xv > 0.0f)) v = 0.0f;
+                dX[m * lddx + c] = v;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < LN_MAXQ; ++q) {
+        const int64_t c = lane + 64 * q;
+        if (c < N) {
+            red[(wv * 2 + 0) * N + c] = dg[q];
+            red[(wv * 2 + 1) * N + c] = db[q];
+        }
+    }
+    __syncthreads();
+    for (int64_t c = threadIdx.x; c < 2 * N; c += 256) {
+        const float v = ((red[0 * 2 * N + c] + red[1 * 2 * N + c]) + red[2 * 2 * N + c]) + red[3 * 2 * N + c];
+        part[(int64_t)blockIdx.x * 2 * N + c] = v;
+    }
+}
+
+// ---- (D^-1 A)^T G: one block row of threads per output node, neighbour weight 1/deg(neighbour)
+__global__ void __launch_bounds__(256)
+k_spmm_mean_bwd(int64_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, const float* __restrict__ G,
+                int64_t ldg, int64_t d, float* __restrict__ out, int64_t ldo) {
+    // 64 threads per node, 4 nodes per block; each thread walks columns lane, lane+64, ...
+    const int lane = threadIdx.x & 63;
+    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= n) return;
+    const int b = rowptr[j], e = rowptr[j + 1];
+    for (int64_t c0 = 0; c0 < d; c0 += 256) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int p = b; p < e; ++p) {
+            const int i = colidx[p];
+            const float inv = 1.0f / (float)(rowptr[i + 1] - rowptr[i]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t c = c0 + lane + 64 * q;
+                if (c < d) acc[q] = __builtin_fmaf(G[(int64_t)i * ldg + c], inv, acc[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t c = c0 + lane + 64 * q;
+            if (c < d) out[j * ldo + c] = acc[q];
+        }
+    }
+}
+
+// ---- d emb.weight[c][col] = sum_{v : idx[v] == c} G[v][col], rows visited in ascending order per wave, 4 waves combined
+__global__ void __launch_bounds__(256)
+k_embedding_bwd(int64_t n, int w, const int32_t* __restrict__ idx, const float* __restrict__ G, int64_t ldg,
+                float* __restrict__ dW, int64_t ldw) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = blockIdx.x;
+    const int col = blockIdx.y * 64 + lane;
+    float acc = 0.0f;
+    for (int64_t v = wv; v < n; v += 4)
+        if (idx[v] == c && col < w) acc = acc + G[v * ldg + col];
+    red[wv][lane] = acc;
+    __syncthreads();
+    if (wv == 0 && col < w) dW[(int64_t)c * ldw + col] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+}
+
+// ---- d h[i] = sum over the batch entries that touch node i (grouped by node, ascending position in cat[src, dst]) of
+//      dZ[b] * h[other end].  order[k] indexes cat[src, dst]: b = order[k] mod B, role = order[k] >= B.
+__global__ void __launch_bounds__(256)
+k_hadamard_gather_bwd(int64_t n, int64_t B, int d, const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+                      const int64_t* __restrict__ segptr, const int64_t* __restrict__ order, const float* __restrict__ h,
+                      int64_t ldh, const float* __restrict__ dZ, int64_t lddz, float* __restrict__ dh, int64_t lddh) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int64_t b0 = segptr[i], b1 = segptr[i + 1];
+    for (int c0 = 0; c0 < d; c0 += 128) {
+        float acc0 = 0.0f, acc1 = 0.0f;
+        const int ca = c0 + lane, cb = c0 + 64 + lane;
+        for (int64_t k = b0; k < b1; ++k) {
+            const int64_t it = order[k];
+            const int64_t b = it >= B ? it - B : it;
+            const int64_t other = it >= B ? src[b] : dst[b];
+            if (ca < d) acc0 = __builtin_fmaf(dZ[b * lddz + ca], h[other * ldh + ca], acc0);
+            if (cb < d) acc1 = __builtin_fmaf(dZ[b * lddz + cb], h[other * ldh + cb], acc1);
+        }
+        if (ca < d) dh[i * lddh + ca] = acc0;
+        if (cb < d) dh[i * lddh + cb] = acc1;
+    }
+}
+
+// ---- 2-class cross entropy, mean over `total` items.  dlogits = (softmax - onehot) / total.  Fixed grid of CE_BLOCKS
+// blocks with grid-stride loops; block partial sums are combined in ascending block order by k_splitk_reduce.
+constexpr int CE_BLOCKS = 1024;
+__global__ void __launch_bounds__(256)
+k_softmax_ce2(int64_t total, const float* __restrict__ logits, const uint8_t* __restrict__ target, float inv_total,
+              float* __restrict__ part, float* __restrict__ dlogits) {
+    __shared__ float red[4];
+    float acc = 0.0f;
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)CE_BLOCKS * 256) {
+        const float2 l = *reinterpret_cast<const float2*>(logits + 2 * g);
+        const int y = target[g] ? 1 : 0;
+        const float m = l.x > l.y ? l.x : l.y;
+        const float e0 = expf_nonpos(l.x - m), e1 = expf_nonpos(l.y - m);
+        const float s = e0 + e1;
+        const float ly = y ? l.y : l.x;
+        acc = acc + ((m + __logf(s)) - ly);
+        if (dlogits) {
+            const float p0 = e0 / s, p1 = e1 / s;
+            *reinterpret_cast<float2*>(dlogits + 2 * g) =
+                make_float2((p0 - (y ? 0.0f : 1.0f)) * inv_total, (p1 - (y ? 1.0f : 0.0f)) * inv_total);
+        }
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (((red[0] + red[1]) + red[2]) + red[3]) * inv_total;
+}
+
+// ---- elementwise pieces of the tape
+__global__ void k_relu_bwd(int64_t total, const float* __restrict__ g, const float* __restrict__ y, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) out[i] = y[i] > 0.0f ? g[i] : 0.0f;
+}
+// nn.Dropout (model/gnn.py:31,37): keep with probability 1-p, scale by 1/(1-p); the mask is a pure function of
+// (seed, call, element index) so the backward regenerates it instead of storing it.  Philox stream 7.
+__global__ void k_dropout(int64_t total, const float* __restrict__ x, float p, float scale, uint64_t seed, uint32_t call,
+                          float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float u = u_idx64(seed, call, 7u, (uint64_t)i);
+    out[i] = u < p ? 0.0f : x[i] * scale;
+}
+__global__ void k_embedding_fwd(int64_t n, int w, const int32_t* __restrict__ idx, const float* __restrict__ table, int64_t ldt,
+                                float* __restrict__ dst, int64_t ldd) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n * w) return;
+    dst[(g / w) * ldd + (g % w)] = table[(int64_t)idx[g / w] * ldt + (g % w)];
+}
+
+// ---- validation: denoising-match KL term (BaseModel.denoise_match_Z, model/diffusion.py:258-303) for 2 classes.
+// Item g uses table g % ntab (ntab = F for attributes laid out (v, f); 1 for edges).  Qt / Qbs: ntab x 4 floats Q[r*2+c].
+//   left[k]  = Q_t[k][z_t]                  (Z_t_one_hot @ Q_t^T)
+//   true[k]  = left[k] * Qbar_s[z_0][k]     / sum_k (0 -> 1)
+//   pred[k]  = left[k] * sum_i p[i] Qbar_s[i][k] / sum_k (0 -> 1)
+//   kl[k]    = true[k] * (log true[k] - log pred[k])   (0 where true[k] == 0), clamped at 0; result = mean over items and k
+__global__ void __launch_bounds__(256)
+k_denoise_match2(int64_t total, const float* __restrict__ logits, const uint8_t* __restrict__ z_t,
+                 const uint8_t* __restrict__ z_0, const float* __restrict__ Qt, const float* __restrict__ Qbs, int64_t ntab,
+                 float inv_count, float* __restrict__ part) {
+    __shared__ float red[4];
+    float acc = 0.0f;
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)CE_BLOCKS * 256) {
+        const float2 l = *reinterpret_cast<const float2*>(logits + 2 * g);
+        float p0, p1;
+        softmax2(l.x, l.y, p0, p1);
+        const float* qt = Qt + 4 * (g % ntab);
+        const float* qs = Qbs + 4 * (g % ntab);
+        const int e = z_t[g] ? 1 : 0, r = z_0[g] ? 1 : 0;
+        const float left0 = qt[0 + e], left1 = qt[2 + e];
+        float t0 = left0 * qs[2 * r], t1 = left1 * qs[2 * r + 1];
+        float dt = t0 + t1;
+        if (dt == 0.0f) dt = 1.0f;
+        t0 = t0 / dt;
+        t1 = t1 / dt;
+        float q0 = left0 * (p0 * qs[0] + p1 * qs[2]), q1 = left1 * (p0 * qs[1] + p1 * qs[3]);
+        float dq = q0 + q1;
+        if (dq == 0.0f) dq = 1.0f;
+        q0 = q0 / dq;
+        q1 = q1 / dq;
+        float k0 = t0 > 0.0f ? t0 * (logf(t0) - logf(q0)) : 0.0f;
+        float k1 = t1 > 0.0f ? t1 * (logf(t1) - logf(q1)) : 0.0f;
+        if (!(k0 > 0.0f)) k0 = 0.0f;
+        if (!(k1 > 0.0f)) k1 = 0.0f;
+        acc = acc + (k0 + k1);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (((red[0] + red[1]) + red[2]) + red[3]) * inv_count;
+}
+
+// out[b] = bit (i[b], j[b]) of the bitmap  (E_t[batch_src, batch_dst], model/diffusion.py:765)
+__global__ void k_bitmap_lookup(int64_t B, const int64_t* __restrict__ i, const int64_t* __restrict__ j,
+                                const uint32_t* __restrict__ bits, int64_t wpr, uint8_t* __restrict__ out) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    out[b] = (bits[i[b] * wpr + (j[b] >> 5)] >> (j[b] & 31)) & 1u;
+}
+
+static inline int pick_splits(int64_t M, int64_t N, int64_t K) {
+    const int64_t tiles = ((M + TBM - 1) / TBM) * ((N + TBN - 1) / TBN);
+    int64_t s = 512 / tiles;
+    const int64_t kmax = K / 256;
+    if (s > kmax) s = kmax;
+    if (s > 1024) s = 1024;
+    return s < 2 ? 1 : (int)s;
+}
+
+}  // namespace gm
+
+using namespace gm;
+
+extern "C" int64_t gm_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    const int s = pick_splits(M, N, K);
+    return s > 1 ? (int64_t)s * M * N * 4 : 0;
+}
+
+extern "C" int gm_gemm(int a_red, int b_red, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+                       int64_t ldb, const float* bias, const float* mask, int64_t ldmask, int relu, float* C, int64_t ldc,
+                       void* workspace, int64_t workspace_bytes, gm_stream_t stream) {
+    GM_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C, "bad arguments");
+    GM_REQUIRE(lda >= (a_red ? M : K) && ldb >= (b_red ? N : K) && ldc >= N, "leading dimension too small");
+    GM_REQUIRE(!mask || ldmask >= N, "mask leading dimension too small");
+    hipStream_t s = as_stream(stream);
+    int splits = pick_splits(M, N, K);
+    int64_t kchunk = K;
+    if (splits > 1) {
+        kchunk = ((K + splits - 1) / splits + TBK - 1) / TBK * TBK;
+        splits = (int)((K + kchunk - 1) / kchunk);
+    }
+    if (splits > 1)
+        GM_REQUIRE(workspace && workspace_bytes >= (int64_t)splits * M * N * 4 && aligned(workspace, 16),
+                   "gm_gemm needs %lld workspace bytes (gm_gemm_workspace_bytes)", (long long)((int64_t)splits * M * N * 4));
+    dim3 grid((unsigned)((N + TBN - 1) / TBN), (unsigned)((M + TBM - 1) / TBM), (unsigned)splits), block(256);
+    GM_REQUIRE(grid.y < 65536u, "M too large");
+    const int vecA = lda % 4 == 0 && aligned(A, 16), vecB = ldb % 4 == 0 && aligned(B, 16);
+    float* out = splits > 1 ? static_cast<float*>(workspace) : C;
+    const int64_t stride = splits > 1 ? M * N : 0;
+#define GM_LAUNCH_G(AR, BR)                                                                                              \
+    hipLaunchKernelGGL((k_gemm_g<AR, BR>), grid, block, 0, s, M, N, K, A, lda, B, ldb, bias, mask, ldmask, relu, out, ldc, \
+                       kchunk, stride, vecA, vecB)
+    if (a_red && b_red) GM_LAUNCH_G(true, true);
+    else if (a_red) GM_LAUNCH_G(true, false);
+    else if (b_red) GM_LAUNCH_G(false, true);
+    else GM_LAUNCH_G(false, false);
+#undef GM_LAUNCH_G
+    GM_LAUNCH_CHECK();
+    if (splits > 1) {
+        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, s, splits, M, N,
+                           static_cast<const float*>(workspace), bias, mask, ldmask, relu, C, ldc);
+        GM_LAUNCH_CHECK();
+    }
+    return GM_OK;
+}
+
+extern "C" int64_t gm_colsum_workspace_bytes(int64_t M, int64_t N) { return ((M + CS_ROWS - 1) / CS_ROWS) * N * 4; }
+
+extern "C" int gm_colsum(int64_t M, int64_t N, const float* X, int64_t ldx, float* out, void* workspace, int64_t workspace_bytes,
+                         gm_stream_t stream) {
+    GM_REQUIRE(M > 0 && N > 0 && X && out && ldx >= N, "bad arguments");
+    const int64_t nblk = (M + CS_ROWS - 1) / CS_ROWS;
+    GM_REQUIRE(workspace && workspace_bytes >= nblk * N * 4, "gm_colsum needs %lld workspace bytes", (long long)(nblk * N * 4));
+    GM_REQUIRE(nblk < 65536, "M too large");
+    hipStream_t s = as_stream(stream);
+    float* part = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(k_colsum_partial, dim3((unsigned)((N + 63) / 64), (unsigned)nblk), dim3(256), 0, s, M, N, X, ldx, part);
+    GM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, (int)nblk, (int64_t)1, N, part,
+                       (const float*)nullptr, (const float*)nullptr, (int64_t)0, 0, out, N);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+extern "C" int gm_layernorm_fwd(int64_t M, int64_t N, const float* X, int64_t ldx, const float* gamma, const float* beta,
+                                float eps, float* Y, int64_t ldy, float* mean, float* rstd, gm_stream_t stream) {
+    GM_REQUIRE(M > 0 && N > 0 && X && gamma && beta && Y && mean && rstd && ldx >= N && ldy >= N, "bad arguments");
+    hipLaunchKernelGGL(k_layernorm_fwd, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, as_stream(stream), M, N, X, ldx, gamma,
+                       beta, eps, Y, ldy, mean, rstd);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+extern "C" int64_t gm_layernorm_bwd_workspace_bytes(int64_t M, int64_t N) { return ((M + LN_ROWS - 1) / LN_ROWS) * 2 * N * 4; }
+
+extern "C" int gm_layernorm_bwd(int64_t M, int64_t N, const float* dY, int64_t lddy, const float* X, int64_t ldx,
+                                const float* mean, const float* rstd, const float* gamma, int relu_mask, float* dX,
+                                int64_t lddx, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes,
+                                gm_stream_t stream) {
+    GM_REQUIRE(M > 0 && N > 0 && dY && X && mean && rstd && gamma && dX && dgamma && dbeta, "bad arguments");
+    GM_REQUIRE(lddy >= N && ldx >= N && lddx >= N, "leading dimension too small");
+    GM_REQUIRE(N <= 64 * LN_MAXQ, "LayerNorm width %lld exceeds %d", (long long)N, 64 * LN_MAXQ);
+    GM_REQUIRE(dbeta == dgamma + N, "dgamma and dbeta must be the two halves of one (2, N) buffer");
+    const int64_t nblk = (M + LN_ROWS - 1) / LN_ROWS;
+    GM_REQUIRE(workspace && workspace_bytes >= nblk * 2 * N * 4, "gm_layernorm_bwd needs %lld workspace bytes",
+               (long long)(nblk * 2 * N * 4));
+    hipStream_t s = as_stream(stream);
+    float* part = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(k_layernorm_bwd, dim3((unsigned)nblk), dim3(256), (size_t)(8 * N * 4), s, M, N, dY, lddy, X, ldx, mean,
+                       rstd, gamma, relu_mask, dX, lddx, part);
+    GM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((2 * N + 255) / 256)), dim3(256), 0, s, (int)nblk, (int64_t)1, 2 * N,
+                       part, (const float*)nullptr, (const float*)nullptr, (int64_t)0, 0, dgamma, 2 * N);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+extern "C" int gm_spmm_mean_bwd(int64_t n, const int32_t* rowptr, const int32_t* colidx, const float* G, int64_t ldg, int64_t d,
+                                float* out, int64_t ldo, gm_stream_t stream) {
+    GM_REQUIRE(n > 0 && d > 0 && rowptr && G && out && ldg >= d && ldo >= d, "bad arguments");
+    hipLaunchKernelGGL(k_spmm_mean_bwd, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, as_stream(stream), n, rowptr, colidx, G, ldg,
+                       d, out, ldo);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+extern "C" int gm_embedding_bwd(int64_t n, int C, int w, const int32_t* idx, const float* G, int64_t ldg, float* dW, int64_t ldw,
+                                gm_stream_t stream) {
+    GM_REQUIRE(n > 0 && C > 0 && w > 0 && idx && G && dW && ldg >= w && ldw >= w, "bad arguments");
+    hipLaunchKernelGGL(k_embedding_bwd, dim3((unsigned)C, (unsigned)((w + 63) / 64)), dim3(256), 0, as_stream(stream), n, w, idx,
+                       G, ldg, dW, ldw);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+extern "C" int gm_hadamard_gather_bwd(int64_t n, int64_t B, int64_t d, const int64_t* src, const int64_t* dst,
+                                      const int64_t* segptr, const int64_t* order, const float* h, int64_t ldh, const float* dZ,
+                                      int64_t lddz, float* dh, int64_t lddh, gm_stream_t stream) {
+    GM_REQUIRE(n > 0 && B > 0 && d > 0 && src && dst && segptr && order && h && dZ && dh, "bad arguments");
+    GM_REQUIRE(ldh >= d && lddz >= d && lddh >= d, "leading dimension too small");
+    hipLaunchKernelGGL(k_hadamard_gather_bwd, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, as_stream(stream), n, B, (int)d, src,
+                       dst, segptr, order, h, ldh, dZ, lddz, dh, lddh);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+extern "C" int64_t gm_softmax_ce2_workspace_bytes(void) { return CE_BLOCKS * 4; }
+
+extern "C" int gm_softmax_ce2(int64_t total, const float* logits, const uint8_t* target, float* loss, float* dlogits,
+                              void* workspace, int64_t workspace_bytes, gm_stream_t stream) {
+    GM_REQUIRE(total > 0 && logits && target && loss && aligned(logits, 8) && (!dlogits || aligned(dlogits, 8)), "bad arguments");
+    GM_REQUIRE(workspace && workspace_bytes >= CE_BLOCKS * 4, "gm_softmax_ce2 needs %d workspace bytes", CE_BLOCKS * 4);
+    hipStream_t s = as_stream(stream);
+    float* part = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(k_softmax_ce2, dim3(CE_BLOCKS), dim3(256), 0, s, total, logits, target, 1.0f / (float)total, part, dlogits);
+    GM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_splitk_reduce, dim3(1), dim3(256), 0, s, CE_BLOCKS, (int64_t)1, (int64_t)1, part, (const float*)nullptr,
+                       (const float*)nullptr, (int64_t)0, 0, loss, (int64_t)1);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+extern "C" int gm_relu_bwd(int64_t total, const float* g, const float* y, float* out, gm_stream_t stream) {
+    GM_REQUIRE(total > 0 && g && y && out, "bad arguments");
+    hipLaunchKernelGGL(k_relu_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), total, g, y, out);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+extern "C" int gm_dropout(int64_t total, const float* x, float p, uint64_t seed, uint32_t call, float* out, gm_stream_t stream) {
+    GM_REQUIRE(total > 0 && x && out && p >= 0.0f && p < 1.0f, "bad arguments (0 <= p < 1)");
+    hipLaunchKernelGGL(k_dropout, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), total, x, p,
+                       1.0f / (1.0f - p), seed, call, out);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+extern "C" int gm_embedding_fwd(int64_t n, int C, int w, const int32_t* idx, const float* weight, int64_t ldw, float* out,
+                                int64_t ldo, gm_stream_t stream) {
+    GM_REQUIRE(n > 0 && C > 0 && w > 0 && idx && weight && out && ldw >= w && ldo >= w, "bad arguments");
+    hipLaunchKernelGGL(k_embedding_fwd, dim3((unsigned)((n * w + 255) / 256)), dim3(256), 0, as_stream(stream), n, w, idx, weight,
+                       ldw, out, ldo);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+extern "C" int gm_denoise_match2(int64_t total, const float* logits, const uint8_t* z_t, const uint8_t* z_0, const float* Q_t,
+                                 const float* Q_bar_s, int64_t ntab, float* out, void* workspace, int64_t workspace_bytes,
+                                 gm_stream_t stream) {
+    GM_REQUIRE(total > 0 && logits && z_t && z_0 && Q_t && Q_bar_s && ntab > 0 && out && aligned(logits, 8), "bad arguments");
+    GM_REQUIRE(workspace && workspace_bytes >= CE_BLOCKS * 4, "gm_denoise_match2 needs %d workspace bytes", CE_BLOCKS * 4);
+    hipStream_t s = as_stream(stream);
+    float* part = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(k_denoise_match2, dim3(CE_BLOCKS), dim3(256), 0, s, total, logits, z_t, z_0, Q_t, Q_bar_s, ntab,
+                       1.0f / (2.0f * (float)total), part);
+    GM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_splitk_reduce, dim3(1), dim3(256), 0, s, CE_BLOCKS, (int64_t)1, (int64_t)1, part, (const float*)nullptr,
+                       (const float*)nullptr, (int64_t)0, 0, out, (int64_t)1);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+extern "C" int gm_bitmap_lookup(int64_t n, int64_t wpr, const uint32_t* bits, int64_t B, const int64_t* i, const int64_t* j,
+                                uint8_t* out, gm_stream_t stream) {
+    GM_REQUIRE(n > 0 && wpr >= (n + 31) / 32 && bits && B > 0 && i && j && out, "bad arguments");
+    hipLaunchKernelGGL(k_bitmap_lookup, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, as_stream(stream), B, i, j, bits, wpr, out);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}

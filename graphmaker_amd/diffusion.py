@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import autograd as ag
 from . import ops, parallel
 from .gnn import GNN, GNNAsymm
 
@@ -102,7 +103,7 @@ class MarginalTransition(nn.Module):
 
 
 class BaseModel(nn.Module):
-    """model/diffusion.py:143-472 (inference half)."""
+    """model/diffusion.py:143-472."""
 
     def __init__(self, T, X_marginal, Y_marginal, E_marginal, num_nodes):
         super().__init__()
@@ -174,6 +175,51 @@ class BaseModel(nn.Module):
         denominator = torch.transpose(Q_bar_t @ torch.transpose(Z_t, -1, -2), -1, -2).unsqueeze(-1).clone()
         denominator[denominator == 0.] = 1.
         return (prior.unsqueeze(-1) * (numerator / denominator)).sum(dim=-2)
+
+    # ---- training / validation plumbing (model/diffusion.py:258-349, 559-604)
+    def _real_state(self, X_one_hot_3d, E_one_hot):
+        """The real graph in library layout, converted once per (tensor, shape): x0 uint8 (N,F), bits0 bitmap."""
+        cache = self.__dict__.setdefault("_real_cache", {})
+        out = []
+        for name, t in (("X", X_one_hot_3d), ("E", E_one_hot)):
+            if t is None:
+                out.append(None)
+                continue
+            key = (name, t.data_ptr(), tuple(t.shape), t._version)
+            if cache.get(name, (None, None))[0] != key:
+                tc = t.contiguous().float()
+                cache[name] = (key, ops.x_from_onehot3d(tc) if name == "X" else ops.bitmap_from_onehot(tc))
+            out.append(cache[name][1])
+        return out
+
+    def _noise_X(self, x0, alpha_bar_t, seed, step, u=None):
+        QX = torch.from_numpy(_transition(alpha_bar_t, self.transition.X_marginal_host).reshape(-1, 4)).to(x0.device)
+        return ops.noise_X(x0, QX, seed=seed, step=step, u=u)
+
+    def _noise_E(self, bits0, alpha_bar_t, seed, step, u=None):
+        Q = _transition(alpha_bar_t, self.transition.E_marginal_host).reshape(4)
+        return ops.noise_E(self.num_nodes, bits0, Q, seed=seed, step=step, u=u)
+
+    def _draw_t(self, t, T, device):
+        """t given (tensor / int) or drawn uniformly from 0..T like model/diffusion.py:582-587; returns (int, tensor)."""
+        if t is None:
+            t = torch.randint(low=0, high=T + 1, size=(1,), device=device)
+        t_int = int(t.item()) if torch.is_tensor(t) else int(t)
+        if not 0 <= t_int <= T:
+            raise ValueError(f"time step {t_int} outside 0..{T}")
+        t_dev = t if torch.is_tensor(t) else torch.tensor([t_int], device=device)
+        return t_int, t_dev
+
+    @staticmethod
+    def _edge_targets(batch_E_one_hot):
+        """argmax of the (B,2) one-hot rows as uint8 (LossE, model/diffusion.py:138)."""
+        return (batch_E_one_hot[:, 1] > batch_E_one_hot[:, 0]).to(torch.uint8).contiguous()
+
+    def _kl_tables(self, ns, t, marginal_host, device):
+        """(Q_t, Q_bar_s) as (ntab,4) device tensors for denoise_match (model/diffusion.py:332-341, 681-690)."""
+        Qt = _transition(ns.alphas_host[t], marginal_host).reshape(-1, 4)
+        Qs = _transition(ns.alpha_bars_host[t - 1], marginal_host).reshape(-1, 4)
+        return torch.from_numpy(Qt).to(device), torch.from_numpy(Qs).to(device)
 
     # ---- sampling plumbing
     def _next_seed(self, seed):
@@ -280,6 +326,57 @@ class ModelSync(BaseModel):
         a_t, ab_s, ab_t = ns.alphas_host[t], ns.alpha_bars_host[t - 1], ns.alpha_bars_host[t]
         return self.transition.table_E(a_t, ab_s, ab_t), self.transition.table_X(a_t, ab_s, ab_t)
 
+    # ---- training / validation (model/diffusion.py:559-795)
+    def _apply_noise_state(self, X_one_hot_3d, E_one_hot, t=None, seed=None, uniforms=None):
+        x0, bits0 = self._real_state(X_one_hot_3d, E_one_hot)
+        t_int, t_dev = self._draw_t(t, self.T, X_one_hot_3d.device)
+        seed = self._next_seed(seed)
+        uni = uniforms or {}
+        ab = self.noise_schedule.alpha_bars_host[t_int]
+        bits_t = self._noise_E(bits0, ab, seed, t_int, u=uni.get("E"))
+        x_t, x_t_onehot = self._noise_X(x0, ab, seed, t_int, u=uni.get("X"))
+        return t_int, t_dev / self.T, x_t, x_t_onehot, bits_t
+
+    def apply_noise(self, X_one_hot_3d, E_one_hot, t=None, *, seed=None, uniforms=None):
+        """model/diffusion.py:559-604: returns (t_float (1,), X_t_one_hot (N,2F), E_t (N,N) int64)."""
+        _, t_float, _, x_t_onehot, bits_t = self._apply_noise_state(X_one_hot_3d, E_one_hot, t, seed, uniforms)
+        return t_float, x_t_onehot, ops.dense_from_bitmap(bits_t, self.num_nodes)
+
+    def log_p_t(self, X_one_hot_3d, E_one_hot, Y, batch_src, batch_dst, batch_E_one_hot, t=None, *, seed=None,
+                uniforms=None):
+        """model/diffusion.py:606-654: corrupt G, run both denoisers, return (loss_X, loss_E) with autograd attached
+        (train_sync.py:98-109)."""
+        x0, _ = self._real_state(X_one_hot_3d, E_one_hot)
+        _, t_float, _, x_t_onehot, bits_t = self._apply_noise_state(X_one_hot_3d, E_one_hot, t, seed, uniforms)
+        A_t = ops.adjacency_from_bitmap(bits_t, self.num_nodes)
+        logit_X, logit_E = self.graph_encoder(t_float, x_t_onehot, Y, A_t, batch_src, batch_dst)
+        loss_X = ag.softmax_ce2(logit_X, x0)                                         # LossX :474-515
+        loss_E = ag.softmax_ce2(logit_E, self._edge_targets(batch_E_one_hot))        # LossE :120-141
+        return loss_X, loss_E
+
+    @torch.no_grad()
+    def val_step(self, X_one_hot_3d, E_one_hot, Y, batch_src, batch_dst, batch_E_one_hot, *, seed=None):
+        """model/diffusion.py:709-795: (denoise_match_E, denoise_match_X, log_p_0_E, log_p_0_X) as floats."""
+        dev = E_one_hot.device
+        x0, bits0 = self._real_state(X_one_hot_3d, E_one_hot)
+        e0 = self._edge_targets(batch_E_one_hot)
+        src, dst = batch_src.contiguous(), batch_dst.contiguous()
+        ns, n = self.noise_schedule, self.num_nodes
+        dm_X, dm_E = [], []
+        for t_sample in range(1, self.T + 1):
+            t_int, t_float, x_t, x_t_onehot, bits_t = self._apply_noise_state(X_one_hot_3d, E_one_hot, t_sample, seed)
+            A_t = ops.adjacency_from_bitmap(bits_t, n)
+            logit_X, logit_E = self.graph_encoder(t_float, x_t_onehot, Y, A_t, src, dst)
+            e_t = ops.bitmap_lookup(bits_t, n, src, dst)                              # E_t[batch_src, batch_dst] :765
+            QtE, QsE = self._kl_tables(ns, t_int, self.transition.E_marginal_host, dev)
+            dm_E.append(ops.denoise_match2(logit_E, e_t, e0, QtE, QsE).item())
+            QtX, QsX = self._kl_tables(ns, t_int, self.transition.X_marginal_host, dev)
+            dm_X.append(ops.denoise_match2(logit_X, x_t, x0, QtX, QsX).item())
+        denoise_match_E = float(np.mean(dm_E)) * self.T
+        denoise_match_X = float(np.mean(dm_X)) * self.T
+        loss_X, loss_E = self.log_p_t(X_one_hot_3d, E_one_hot, Y, src, dst, batch_E_one_hot, 0, seed=seed)
+        return denoise_match_E, denoise_match_X, loss_E.item(), loss_X.item()
+
     @torch.no_grad()
     def denoise_step(self, t, x, x_onehot, Y32, bits_t, seed, uniforms=None, plan=None, group=None):
         """One reverse step t -> t-1 (the body of the loop at model/diffusion.py:847-896).
@@ -342,6 +439,68 @@ class ModelAsync(BaseModel):
     def table_E(self, t):
         ns = self.noise_schedule_E
         return self.transition.table_E(ns.alphas_host[t], ns.alpha_bars_host[t - 1], ns.alpha_bars_host[t])
+
+    # ---- training / validation (model/diffusion.py:962-1293)
+    def _apply_noise_X_state(self, X_one_hot_3d, t=None, seed=None, u=None):
+        x0, _ = self._real_state(X_one_hot_3d, None)
+        t_int, t_dev = self._draw_t(t, self.T_X, X_one_hot_3d.device)
+        x_t, x_t_onehot = self._noise_X(x0, self.noise_schedule_X.alpha_bars_host[t_int], self._next_seed(seed), t_int, u=u)
+        return t_int, t_dev / self.T_X, x_t, x_t_onehot
+
+    def _apply_noise_E_state(self, E_one_hot, t=None, seed=None, u=None):
+        _, bits0 = self._real_state(None, E_one_hot)
+        t_int, t_dev = self._draw_t(t, self.T_E, E_one_hot.device)
+        bits_t = self._noise_E(bits0, self.noise_schedule_E.alpha_bars_host[t_int], self._next_seed(seed), t_int, u=u)
+        return t_int, t_dev / self.T_E, bits_t
+
+    def apply_noise_X(self, X_one_hot_3d, t=None, *, seed=None, u=None):
+        """model/diffusion.py:962-996: (t_float_X, X_t_one_hot)."""
+        _, t_float, _, x_t_onehot = self._apply_noise_X_state(X_one_hot_3d, t, seed, u)
+        return t_float, x_t_onehot
+
+    def apply_noise_E(self, E_one_hot, t=None, *, seed=None, u=None):
+        """model/diffusion.py:998-1033: (t_float_E, E_t (N,N) int64)."""
+        _, t_float, bits_t = self._apply_noise_E_state(E_one_hot, t, seed, u)
+        return t_float, ops.dense_from_bitmap(bits_t, self.num_nodes)
+
+    def log_p_t(self, X_one_hot_3d, E_one_hot, Y, X_one_hot_2d, batch_src, batch_dst, batch_E_one_hot, t_X=None, t_E=None, *,
+                seed=None, uniforms=None):
+        """model/diffusion.py:1035-1094."""
+        uni = uniforms or {}
+        x0, _ = self._real_state(X_one_hot_3d, E_one_hot)
+        _, t_float_X, _, x_t_onehot = self._apply_noise_X_state(X_one_hot_3d, t_X, seed, uni.get("X"))
+        _, t_float_E, bits_t = self._apply_noise_E_state(E_one_hot, t_E, seed, uni.get("E"))
+        A_t = ops.adjacency_from_bitmap(bits_t, self.num_nodes)
+        logit_X, logit_E = self.graph_encoder(t_float_X, t_float_E, x_t_onehot, Y, X_one_hot_2d, A_t, batch_src, batch_dst)
+        loss_X = ag.softmax_ce2(logit_X, x0)
+        loss_E = ag.softmax_ce2(logit_E, self._edge_targets(batch_E_one_hot))
+        return loss_X, loss_E
+
+    @torch.no_grad()
+    def val_step(self, X_one_hot_3d, E_one_hot, Y, X_one_hot_2d, batch_src, batch_dst, batch_E_one_hot, *, seed=None):
+        """model/diffusion.py:1196-1293."""
+        dev = E_one_hot.device
+        x0, bits0 = self._real_state(X_one_hot_3d, E_one_hot)
+        e0 = self._edge_targets(batch_E_one_hot)
+        src, dst = batch_src.contiguous(), batch_dst.contiguous()
+        n = self.num_nodes
+        dm_X, dm_E = [], []
+        for t_sample in range(1, self.T_X + 1):
+            t_int, t_float, x_t, x_t_onehot = self._apply_noise_X_state(X_one_hot_3d, t_sample, seed)
+            logit_X = self.graph_encoder.pred_X(t_float, x_t_onehot, Y)
+            QtX, QsX = self._kl_tables(self.noise_schedule_X, t_int, self.transition.X_marginal_host, dev)
+            dm_X.append(ops.denoise_match2(logit_X, x_t, x0, QtX, QsX).item())
+        denoise_match_X = float(np.mean(dm_X)) * self.T_X
+        for t_sample in range(1, self.T_E + 1):
+            t_int, t_float, bits_t = self._apply_noise_E_state(E_one_hot, t_sample, seed)
+            A_t = ops.adjacency_from_bitmap(bits_t, n)
+            logit_E = self.graph_encoder.pred_E(t_float, X_one_hot_2d, Y, A_t, src, dst)
+            e_t = ops.bitmap_lookup(bits_t, n, src, dst)
+            QtE, QsE = self._kl_tables(self.noise_schedule_E, t_int, self.transition.E_marginal_host, dev)
+            dm_E.append(ops.denoise_match2(logit_E, e_t, e0, QtE, QsE).item())
+        denoise_match_E = float(np.mean(dm_E)) * self.T_E
+        loss_X, loss_E = self.log_p_t(X_one_hot_3d, E_one_hot, Y, X_one_hot_2d, src, dst, batch_E_one_hot, 0, 0, seed=seed)
+        return denoise_match_E, denoise_match_X, loss_E.item(), loss_X.item()
 
     @torch.no_grad()
     def attribute_step(self, t, x, x_onehot, Y32, seed, uniforms=None, plan=None, group=None):

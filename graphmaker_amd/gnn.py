@@ -2,14 +2,18 @@
 keys (reference: model/gnn.py), executed by libgraphmaker_hip.so.
 
 The nn.Module objects here only HOLD parameters (so `load_state_dict` of a reference Sync/Async checkpoint works
-key for key, sample.py:64-65,78-79); every forward is a call into the HIP library.  Inference only: the kernels
-have no backward yet (training drop-in is the next scope row).
+key for key, sample.py:64-65,78-79); every forward is a call into the HIP library.
+
+Two execution modes with the same arithmetic: without autograd (sampling, validation) a tower is ONE fused library
+call (gm_tower_forward); with autograd enabled and trainable parameters (log_p_t, train_sync.py:98-109) the same
+operators are issued one by one through graphmaker_amd.autograd, whose backward halves are HIP kernels too.
 """
 import ctypes as C
 
 import torch
 import torch.nn as nn
 
+from . import autograd as ag
 from . import ops
 from ._lib import TowerDims
 
@@ -80,9 +84,47 @@ class _TowerBase(nn.Module):
             self._ws = torch.empty(need, dtype=torch.uint8, device=device)
         return self._ws
 
+    def _on_tape(self):
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
+    def _run_tape(self, t_float, X_t_one_hot, Y_real, A_t):
+        """The tower operator by operator with autograd recording (model/gnn.py:146-176 / :440-463); returns (n, out)."""
+        def lin(m, x, relu):
+            return ag.linear(x, m.weight, m.bias, relu)
+
+        n = X_t_one_hot.shape[0]
+        Y32 = (Y_real if Y_real.dtype == torch.int32 else Y_real.to(torch.int32)).contiguous()
+        t = t_float.reshape(1, 1).to(torch.float32)
+        h_t = lin(self.mlp_in_t[2], lin(self.mlp_in_t[0], t, True), True)                     # (1, hidden_t)
+        h_X = lin(self.mlp_in_X[2], lin(self.mlp_in_X[0], X_t_one_hot, True), True)
+        h_Y = ag.embedding(self.emb_Y.weight, Y32)
+        h_t_exp = h_t.expand(n, -1)
+        hX_list, hY_list = [h_X], [h_Y]
+        hX_w = h_X.shape[1]
+        if not hasattr(self, "_dropout_state"):
+            self._dropout_state = ag.DropoutState(torch.initial_seed())
+        for layer in getattr(self, self._layers_attr):
+            if self._is_mlp:                                                                   # model/gnn.py:386-392
+                in_X, in_Y = torch.cat([h_X, h_Y, h_t_exp], dim=1), h_Y
+            else:                                                                              # model/gnn.py:60-68
+                agg = ag.spmm_mean(A_t, torch.cat([h_X, h_Y], dim=1))
+                in_X, in_Y = torch.cat([agg, h_t_exp], dim=1), agg[:, hX_w:]                   # A @ h_Y = columns of A @ [h_X|h_Y]
+            ux, uy = layer.update_X, layer.update_Y
+            h_X = ag.update_block(in_X, ux[0].weight, ux[0].bias, ux[2].weight, ux[2].bias, ux[2].eps)
+            h_Y = ag.update_block(in_Y, uy[0].weight, uy[0].bias, uy[2].weight, uy[2].bias, uy[2].eps)
+            if self.training:
+                h_X = ag.dropout(h_X, ux[3].p, self._dropout_state)
+                h_Y = ag.dropout(h_Y, uy[3].p, self._dropout_state)
+            hX_list.append(h_X)
+            hY_list.append(h_Y)
+        h_cat = torch.cat(hX_list + hY_list + [h_t_exp], dim=1)
+        return lin(self.mlp_out[2], lin(self.mlp_out[0], h_cat, True), False)
+
     def _run(self, t_float, X_t_one_hot, Y_real, A_t, want_hcat=False, rows=None, out=None):
+        if self._on_tape() and not want_hcat and rows is None and out is None:
+            return self._run_tape(t_float, X_t_one_hot, Y_real, A_t)
         if self.training and any(m.p > 0 for m in self.modules() if isinstance(m, nn.Dropout)):
-            raise NotImplementedError("graphmaker_amd towers run in eval mode only (dropout is not implemented)")
+            raise NotImplementedError("the fused tower call has no dropout: use train mode with autograd enabled, or eval()")
         n = X_t_one_hot.shape[0]
         X = X_t_one_hot if X_t_one_hot.is_contiguous() else X_t_one_hot.contiguous()
         Y32 = Y_real if Y_real.dtype == torch.int32 else Y_real.to(torch.int32)
@@ -130,7 +172,6 @@ class GNNTower(_TowerBase):
                     dropout)
         self.node_mode = node_mode
 
-    @torch.no_grad()
     def forward(self, t_float, X_t_one_hot, Y_real, A_t):
         if not isinstance(A_t, ops.Adjacency):
             raise TypeError("A_t must come from graphmaker_amd get_adj()/ops.adjacency_from_bitmap()")
@@ -151,7 +192,6 @@ class MLPTower(_TowerBase):
         self._build(num_attrs_X, num_classes_X, num_classes_Y, hidden_t, hidden_X, hidden_Y,
                     num_attrs_X * num_classes_X, num_mlp_layers, dropout)
 
-    @torch.no_grad()
     def forward(self, t_float, X_t_one_hot, Y_real):
         out = self._run(t_float, X_t_one_hot, Y_real, None)
         return out.reshape(Y_real.size(0), self.num_attrs_X, -1)           # model/gnn.py:461
@@ -170,11 +210,13 @@ class LinkPredictor(nn.Module):
     def pair_params(self):
         return (self.mlp_out[0].weight, self.mlp_out[0].bias, self.mlp_out[2].weight, self.mlp_out[2].bias)
 
-    @torch.no_grad()
     def forward(self, t_float, X_t_one_hot, Y_real, A_t, src, dst):
         h = self.gnn_encoder(t_float, X_t_one_hot, Y_real, A_t)
-        z = ops.hadamard_gather(h, src.contiguous(), dst.contiguous())     # model/gnn.py:246
         W1, b1, W2, b2 = self.pair_params()
+        if torch.is_grad_enabled() and (h.requires_grad or W1.requires_grad):
+            z = ag.hadamard_gather(h, src, dst)
+            return ag.linear(ag.linear(z, W1, b1, True), W2, b2, False)
+        z = ops.hadamard_gather(h, src.contiguous(), dst.contiguous())     # model/gnn.py:246
         return ops.linear(ops.linear(z, W1, b1, relu=True), W2, b2)        # model/gnn.py:248
 
 

@@ -241,3 +241,88 @@ def prior_E(n, p0, p1, device, *, seed=0, u=None):
     bits = torch.empty((n, wpr), dtype=torch.int32, device=device)
     L.call("gm_prior_E", I64(n), I64(wpr), F32(p0), F32(p1), ptr(u), U64(seed), ptr(upper), ptr(bits), stream_ptr())
     return bits
+
+
+# ------------------------------------------------------------------ forward noising / training-side converters
+def noise_E(n, bits0, Q_bar_t, *, seed=0, step=0, u=None):
+    """q(E^t | E): symmetric bitmap of E_t (model/diffusion.py:591-594).  Q_bar_t: 4 host floats Q[r*2+c]."""
+    require(bits0, torch.int32, "bits0")
+    wpr = bits0.shape[1]
+    upper = torch.empty_like(bits0)
+    bits = torch.empty_like(bits0)
+    Q = (C.c_float * 4)(*[float(q) for q in Q_bar_t])
+    if u is not None:
+        require(u, torch.float32, "u")
+        if u.numel() != n * n:
+            raise ValueError(f"u has {u.numel()} entries, expected n*n={n * n}")
+    L.call("gm_noise_E", I64(n), I64(wpr), ptr(bits0), Q, ptr(u), U64(seed), U32(step), ptr(upper), ptr(bits), stream_ptr())
+    return bits
+
+
+def noise_X(x0, Q_bar_t_X, *, seed=0, step=0, u=None):
+    """q(X^t | X): (x_t uint8 (N,F), one-hot float (N,2F)) (model/diffusion.py:596-600).  Q_bar_t_X: (F,4) device."""
+    require(x0, torch.uint8, "x0")
+    require(Q_bar_t_X, torch.float32, "Q_bar_t_X")
+    n, F = x0.shape
+    if Q_bar_t_X.numel() != 4 * F:
+        raise ValueError(f"Q_bar_t_X has {Q_bar_t_X.numel()} entries, expected 4F={4 * F}")
+    if u is not None:
+        require(u, torch.float32, "u")
+        if u.numel() != n * F:
+            raise ValueError(f"u has {u.numel()} entries, expected n*F={n * F}")
+    x_t = torch.empty_like(x0)
+    oh = torch.empty((n, 2 * F), dtype=torch.float32, device=x0.device)
+    L.call("gm_noise_X", I64(n), I64(F), ptr(x0), ptr(Q_bar_t_X), ptr(u), U64(seed), U32(step), ptr(x_t), ptr(oh), stream_ptr())
+    return x_t, oh
+
+
+def bitmap_from_onehot(E_one_hot):
+    require(E_one_hot, torch.float32, "E_one_hot")
+    n = E_one_hot.shape[0]
+    if tuple(E_one_hot.shape) != (n, n, 2):
+        raise ValueError(f"E_one_hot is {tuple(E_one_hot.shape)}, expected (N,N,2)")
+    wpr = words_per_row(n)
+    bits = torch.empty((n, wpr), dtype=torch.int32, device=E_one_hot.device)
+    L.call("gm_bitmap_from_onehot_f32", I64(n), I64(wpr), ptr(E_one_hot), ptr(bits), stream_ptr())
+    return bits
+
+
+def x_from_onehot3d(X_one_hot_3d):
+    require(X_one_hot_3d, torch.float32, "X_one_hot_3d")
+    F, n, c = X_one_hot_3d.shape
+    if c != 2:
+        raise ValueError("binary attributes only")
+    x = torch.empty((n, F), dtype=torch.uint8, device=X_one_hot_3d.device)
+    L.call("gm_x_from_onehot3d", I64(n), I64(F), ptr(X_one_hot_3d), ptr(x), stream_ptr())
+    return x
+
+
+def bitmap_lookup(bits, n, i, j):
+    require(bits, torch.int32, "bits")
+    require(i, torch.int64, "i")
+    require(j, torch.int64, "j")
+    out = torch.empty(i.numel(), dtype=torch.uint8, device=bits.device)
+    L.call("gm_bitmap_lookup", I64(n), I64(bits.shape[1]), ptr(bits), I64(i.numel()), ptr(i), ptr(j), ptr(out), stream_ptr())
+    return out
+
+
+_ce_ws = {}
+
+
+def denoise_match2(logits, z_t, z_0, Q_t, Q_bar_s):
+    """Denoising-match KL (BaseModel.denoise_match_Z, model/diffusion.py:258-303) -> (1,) device tensor."""
+    logits = logits.contiguous()
+    require(logits, torch.float32, "logits")
+    require(z_t, torch.uint8, "z_t")
+    require(z_0, torch.uint8, "z_0")
+    total = z_t.numel()
+    if logits.numel() != 2 * total or z_0.numel() != total:
+        raise ValueError("denoise_match2: logits / z_t / z_0 sizes disagree")
+    dev = logits.device
+    if dev not in _ce_ws:
+        _ce_ws[dev] = torch.empty(4096, dtype=torch.uint8, device=dev)
+    ws = _ce_ws[dev]
+    out = torch.empty(1, dtype=torch.float32, device=dev)
+    L.call("gm_denoise_match2", I64(total), ptr(logits), ptr(z_t), ptr(z_0), ptr(Q_t), ptr(Q_bar_s), I64(Q_t.numel() // 4),
+           ptr(out), ptr(ws), I64(ws.numel()), stream_ptr())
+    return out

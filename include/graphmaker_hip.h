@@ -147,6 +147,78 @@ int gm_prior_X(int64_t n, int64_t F, const float* X_marginal, const float* u, ui
 int gm_prior_E(int64_t n, int64_t wpr, float p0, float p1, const float* u, uint64_t seed, uint32_t* upper_ws,
                uint32_t* bits, gm_stream_t stream);
 
+/* ---- forward noising q(G^t | G): model/diffusion.py:559-604 (Sync apply_noise), :962-1033 (Async apply_noise_X/_E) ----
+ * Philox streams 5 (E, idx = i*n+j for j >= i, diagonal drawn and kept like sample_E :188-212) and 6 (X, idx = f*n+v);
+ * `step` is the caller's draw counter (any value; two calls with the same seed and step repeat the draw).
+ * Q_bar_t: host pointer, 4 floats Q[r*2+c] (get_Q_bar_E :52-67).  Q_bar_t_X: device pointer, F*4 floats (:69-84). */
+int gm_noise_E(int64_t n, int64_t wpr, const uint32_t* bits0, const float* Q_bar_t, const float* u, uint64_t seed,
+               uint32_t step, uint32_t* upper_ws, uint32_t* bits_t, gm_stream_t stream);
+int gm_noise_X(int64_t n, int64_t F, const uint8_t* x0, const float* Q_bar_t_X, const float* u, uint64_t seed,
+               uint32_t step, uint8_t* x_t, float* onehot_out, gm_stream_t stream);
+/* the reference's dense training tensors -> library state: E_one_hot (N,N,2) float (data.py:73-76) -> bitmap,
+ * X_one_hot_3d (F,N,2) float (data.py:65-71) -> uint8 x[N][F] */
+int gm_bitmap_from_onehot_f32(int64_t n, int64_t wpr, const float* E_one_hot, uint32_t* bits, gm_stream_t stream);
+int gm_x_from_onehot3d(int64_t n, int64_t F, const float* X_one_hot_3d, uint8_t* x, gm_stream_t stream);
+
+/* ---- training step log_p_t (model/diffusion.py:606-654, :1035-1094; train_sync.py:94-120): operator backward halves.
+ * torch.autograd in the reference; here every gradient is a kernel with a fixed reduction order (reproducible). */
+/* C[m][n] = act( sum_k a(m,k) b(n,k) + bias[n] ), zeroed where mask[m][n] <= 0 (ReLU backward);
+ * a(m,k) = a_red ? A[k*lda+m] : A[m*lda+k];  b(n,k) = b_red ? B[k*ldb+n] : B[n*ldb+k].
+ * nn.Linear (model/gnn.py:27-38): forward (0,0) A=X B=W; dX = dY W -> (0,1) A=dY B=W; dW = dY^T X -> (1,1) A=dY B=X.
+ * Small outputs with a long reduction are split over K into `workspace` and summed in ascending split order. */
+int64_t gm_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int gm_gemm(int a_red, int b_red, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+            int64_t ldb, const float* bias, const float* mask, int64_t ldmask, int relu, float* C, int64_t ldc,
+            void* workspace, int64_t workspace_bytes, gm_stream_t stream);
+/* out[n] = sum_m X[m][n]  (bias gradient) */
+int64_t gm_colsum_workspace_bytes(int64_t M, int64_t N);
+int gm_colsum(int64_t M, int64_t N, const float* X, int64_t ldx, float* out, void* workspace, int64_t workspace_bytes,
+              gm_stream_t stream);
+/* nn.LayerNorm (model/gnn.py:30,36) out of place, statistics saved for the backward */
+int gm_layernorm_fwd(int64_t M, int64_t N, const float* X, int64_t ldx, const float* gamma, const float* beta,
+                     float eps, float* Y, int64_t ldy, float* mean, float* rstd, gm_stream_t stream);
+/* dX (zeroed where X <= 0 when relu_mask: the ReLU in front of the LayerNorm), dgamma, dbeta = dgamma + N */
+int64_t gm_layernorm_bwd_workspace_bytes(int64_t M, int64_t N);
+int gm_layernorm_bwd(int64_t M, int64_t N, const float* dY, int64_t lddy, const float* X, int64_t ldx,
+                     const float* mean, const float* rstd, const float* gamma, int relu_mask, float* dX,
+                     int64_t lddx, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes,
+                     gm_stream_t stream);
+/* backward of gm_spmm_mean for a symmetric adjacency: out[j] = sum_{i in N(j)} G[i] / deg(i)  (model/gnn.py:60-61) */
+int gm_spmm_mean_bwd(int64_t n, const int32_t* rowptr, const int32_t* colidx, const float* G, int64_t ldg, int64_t d,
+                     float* out, int64_t ldo, gm_stream_t stream);
+/* d emb_Y.weight (C, w) of the label embedding (model/gnn.py:155): dW[c] = sum_{v: idx[v]==c} G[v] */
+int gm_embedding_bwd(int64_t n, int C, int w, const int32_t* idx, const float* G, int64_t ldg, float* dW, int64_t ldw,
+                     gm_stream_t stream);
+/* d h of z[b] = h[src[b]] * h[dst[b]] (model/gnn.py:246).  order (2B): stable sort permutation of cat[src, dst] by
+ * node; segptr (n+1): start of each node's run in `order`.  No atomics: one wave per node walks its run in order. */
+int gm_hadamard_gather_bwd(int64_t n, int64_t B, int64_t d, const int64_t* src, const int64_t* dst,
+                           const int64_t* segptr, const int64_t* order, const float* h, int64_t ldh, const float* dZ,
+                           int64_t lddz, float* dh, int64_t lddh, gm_stream_t stream);
+/* out = g where y > 0 else 0 (nn.ReLU backward, model/gnn.py:29,35,118,124,140) */
+int gm_relu_bwd(int64_t total, const float* g, const float* y, float* out, gm_stream_t stream);
+/* nn.Dropout (model/gnn.py:31,37) in training mode: out = x/(1-p) where u >= p else 0, u = Philox stream 7 at element
+ * index with counter word `call`; the same (seed, call) applied to the gradient is the backward */
+int gm_dropout(int64_t total, const float* x, float p, uint64_t seed, uint32_t call, float* out, gm_stream_t stream);
+/* nn.Embedding forward (emb_Y, model/gnn.py:155): out[v] = weight[idx[v]]; idx must lie in [0, C) */
+int gm_embedding_fwd(int64_t n, int C, int w, const int32_t* idx, const float* weight, int64_t ldw, float* out,
+                     int64_t ldo, gm_stream_t stream);
+/* F.cross_entropy over 2 classes, mean over `total` items (LossX / LossE, model/diffusion.py:120-141, 474-515):
+ * loss[0] = mean(logsumexp(l) - l[target]); dlogits (optional) = (softmax(l) - onehot(target)) / total */
+int64_t gm_softmax_ce2_workspace_bytes(void);
+int gm_softmax_ce2(int64_t total, const float* logits, const uint8_t* target, float* loss, float* dlogits,
+                   void* workspace, int64_t workspace_bytes, gm_stream_t stream);
+
+/* ---- validation (val_step, model/diffusion.py:709-795, :1196-1293) ----
+ * denoising-match KL of BaseModel.denoise_match_Z (:258-303) for 2 classes: out[0] = mean over items and classes of
+ * clamp(KL element, 0).  Item g uses transition tables g % ntab (ntab = F for attributes laid out (v,f), 1 for edges);
+ * Q_t, Q_bar_s: device, ntab*4 floats Q[r*2+c].  workspace: gm_softmax_ce2_workspace_bytes(). */
+int gm_denoise_match2(int64_t total, const float* logits, const uint8_t* z_t, const uint8_t* z_0, const float* Q_t,
+                      const float* Q_bar_s, int64_t ntab, float* out, void* workspace, int64_t workspace_bytes,
+                      gm_stream_t stream);
+/* out[b] = E[i[b]][j[b]] read from the bitmap (E_t[batch_src, batch_dst], :765); ids must lie in [0, n) */
+int gm_bitmap_lookup(int64_t n, int64_t wpr, const uint32_t* bits, int64_t B, const int64_t* i, const int64_t* j,
+                     uint8_t* out, gm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -251,6 +251,37 @@ void gmo_prior_E(int64_t n, int64_t wpr, float p0, float p1, const float* u_or_n
         }
 }
 
+/* ------------------------------------------------------------------ forward noising q(G^t | G) */
+/* model/diffusion.py:591-594 (+ sample_E :188-212): prob_E = E_one_hot @ Q_bar_t, one draw per (i, j >= i), the
+ * diagonal included, mirrored to the lower triangle.  Q: Q_bar_t[r*2+c].  Philox stream 5, idx = i*n+j. */
+void gmo_noise_E(int64_t n, int64_t wpr, const uint32_t* bits0, const float Q[4], const float* u_or_null,
+                 uint64_t seed, uint32_t step, uint32_t* bits_t) {
+    memset(bits_t, 0, sizeof(uint32_t) * (size_t)(n * wpr));
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = i; j < n; ++j) {
+            int64_t idx = i * n + j;
+            float u = u_or_null ? u_or_null[idx] : u_idx64(seed, step, GMO_STREAM_E_NOISE, (uint64_t)idx);
+            int e0 = (bits0[i * wpr + (j >> 5)] >> (j & 31)) & 1u;
+            if (draw2(u, Q[2 * e0], Q[2 * e0 + 1])) {
+                bits_t[i * wpr + (j >> 5)] |= 1u << (j & 31);
+                bits_t[j * wpr + (i >> 5)] |= 1u << (i & 31);
+            }
+        }
+}
+/* model/diffusion.py:596-600 (+ sample_X :214-237): prob_X = bmm(X_one_hot_3d, Q_bar_t_X).  QX: F x 4.
+ * Philox stream 6, idx = f*n+v. */
+void gmo_noise_X(int64_t n, int64_t F, const uint8_t* x0, const float* QX, const float* u_or_null, uint64_t seed,
+                 uint32_t step, uint8_t* x_t) {
+#pragma omp parallel for schedule(static)
+    for (int64_t v = 0; v < n; ++v)
+        for (int64_t f = 0; f < F; ++f) {
+            int64_t idx = f * n + v;
+            float u = u_or_null ? u_or_null[idx] : u_idx64(seed, step, GMO_STREAM_X_NOISE, (uint64_t)idx);
+            int r = x0[v * F + f] ? 1 : 0;
+            x_t[v * F + f] = (uint8_t)draw2(u, QX[4 * f + 2 * r], QX[4 * f + 2 * r + 1]);
+        }
+}
+
 /* ------------------------------------------------------------------ adjacency */
 void gmo_bitmap_from_dense_i64(int64_t n, int64_t wpr, const int64_t* dense, uint32_t* bits) {
     memset(bits, 0, sizeof(uint32_t) * (size_t)(n * wpr));

@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-enum { GMO_STREAM_Y = 1, GMO_STREAM_X = 2, GMO_STREAM_E_PRIOR = 3, GMO_STREAM_E = 4 };
+enum { GMO_STREAM_Y = 1, GMO_STREAM_X = 2, GMO_STREAM_E_PRIOR = 3, GMO_STREAM_E = 4, GMO_STREAM_E_NOISE = 5,
+       GMO_STREAM_X_NOISE = 6 };
 
 typedef struct {
     int in_X;        /* num_attrs_X * num_classes_X = 2F      (model/gnn.py:112) */
@@ -85,6 +86,12 @@ void gmo_prior_X(int64_t n, int64_t F, const float* X_marginal, const float* u_o
                  uint8_t* x);
 void gmo_prior_E(int64_t n, int64_t wpr, float p0, float p1, const float* u_or_null, uint64_t seed,
                  uint32_t* bits /* symmetric, diagonal kept */);
+
+/* ---- forward noising (model/diffusion.py:559-604, 962-1033) ---- */
+void gmo_noise_E(int64_t n, int64_t wpr, const uint32_t* bits0, const float Q_bar_t[4], const float* u_or_null,
+                 uint64_t seed, uint32_t step, uint32_t* bits_t /* symmetric, diagonal draws kept */);
+void gmo_noise_X(int64_t n, int64_t F, const uint8_t* x0, const float* Q_bar_t_X /* F*4 */, const float* u_or_null,
+                 uint64_t seed, uint32_t step, uint8_t* x_t);
 
 /* ---- adjacency (model/diffusion.py:239-256, 408-426) ---- */
 void gmo_bitmap_from_dense_i64(int64_t n, int64_t wpr, const int64_t* dense, uint32_t* bits);

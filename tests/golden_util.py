@@ -119,3 +119,37 @@ def load_golden(name):
 
 def case_json(name):
     return json.dumps(CASES[name], sort_keys=True)
+
+
+# ---------------------------------------------------------------- training fixtures (tools/gen_golden_train.py)
+TRAIN_CASES = ("sync_small", "async_mid")
+
+
+def real_graph(cfg):
+    """A synthetic "real" graph for the training path: x0 (N,F) uint8 drawn from the marginals, labels Y (N,) int64,
+    symmetric adjacency E0 (N,N) int64 with the case's density and an empty diagonal (data.py:17 removes self loops)."""
+    rs = np.random.RandomState(cfg["seed"] + 2000)
+    N, F, C = cfg["N"], cfg["F"], cfg["C"]
+    Xm, _, _ = marginals(cfg)
+    x0 = (rs.uniform(size=(N, F)) < Xm[:, 1][None, :]).astype(np.uint8)
+    Y = rs.randint(0, C, size=N).astype(np.int64)
+    up = np.triu(rs.uniform(size=(N, N)) < cfg["density"], k=1)
+    E0 = (up | up.T).astype(np.int64)
+    return x0, Y, E0
+
+
+def train_batch(cfg, B=1500):
+    """(batch_dst, batch_src) as train_sync.py:44-46,97 builds them: rows of triu_indices(N, N, offset=1), a fixed
+    random subset in random order."""
+    rs = np.random.RandomState(cfg["seed"] + 3000)
+    N = cfg["N"]
+    iu, ju = np.triu_indices(N, k=1)
+    pick = rs.permutation(len(iu))[:min(B, len(iu))]
+    return iu[pick].astype(np.int64), ju[pick].astype(np.int64)       # dst = row index, src = column index
+
+
+def train_uniforms(cfg, kind, t):
+    """Host-supplied uniforms (24-bit grid) of the forward-noising draws: kind "E" -> (N*N,), "X" -> (F*N,)."""
+    rs = np.random.RandomState(cfg["seed"] + 4000 + 17 * t + (0 if kind == "E" else 7))
+    n = cfg["N"] * cfg["N"] if kind == "E" else cfg["N"] * cfg["F"]
+    return (rs.randint(0, 1 << 24, size=n).astype(np.float32) * np.float32(2.0 ** -24)).astype(np.float32)

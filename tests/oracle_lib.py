@@ -180,6 +180,25 @@ def prior_E(n, E_marginal, u=None, seed=0, wpr=None):
     return bits
 
 
+# ---------------------------------------------------------------- forward noising
+def noise_E(n, bits0, Q_bar_t, u=None, seed=0, step=0):
+    bits0 = np.ascontiguousarray(bits0, dtype=np.uint32)
+    Q = f32(np.asarray(Q_bar_t).reshape(4))
+    bits = np.empty_like(bits0)
+    lib().gmo_noise_E(C.c_int64(n), C.c_int64(bits0.shape[1]), _p(bits0), _p(Q), _p(u), C.c_uint64(seed),
+                      C.c_uint32(step), _p(bits))
+    return bits
+
+
+def noise_X(x0, Q_bar_t_X, u=None, seed=0, step=0):
+    x0 = np.ascontiguousarray(x0, dtype=np.uint8)
+    n, F = x0.shape
+    Q = f32(np.asarray(Q_bar_t_X).reshape(F, 4))
+    x_t = np.empty_like(x0)
+    lib().gmo_noise_X(C.c_int64(n), C.c_int64(F), _p(x0), _p(Q), _p(u), C.c_uint64(seed), C.c_uint32(step), _p(x_t))
+    return x_t
+
+
 # ---------------------------------------------------------------- adjacency
 def bitmap_from_dense(dense, wpr=None):
     d = np.ascontiguousarray(dense, dtype=np.int64)
