@@ -15,6 +15,14 @@ import oracle_lib as orc
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _inference_mode():
+    """The sampling path runs under torch.no_grad() (model/diffusion.py:797, sample.py:81); direct tower calls in these
+    tests do the same, so they take the fused gm_tower_forward path rather than the autograd tape."""
+    with torch.no_grad():
+        yield
+
 LOGIT_ATOL, POST_ATOL, RTOL, KNIFE = 2e-5, 2e-6, 1e-5, 1e-5
 EXACT = True   # HIP vs oracle: identical accumulation orders -> identical bits
 

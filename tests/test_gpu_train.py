@@ -405,3 +405,28 @@ def test_tape_forward_equals_fused_forward(dev):
         taped = tower(t, oh, d["Y"], A)
         assert taped.requires_grad and not fused.requires_grad
         assert torch.equal(taped.detach(), fused)
+
+
+# ------------------------------------------------------------------ the two callers end to end (local files)
+def test_cli_train_then_sample(dev, tmp_path):
+    """python -m graphmaker_amd train ... -> reference-format .pth -> python -m graphmaker_amd sample ..."""
+    import os
+    from graphmaker_amd import __main__ as cli
+    from graphmaker_amd import data as gdata
+    from test_host_io_cpu import SYNC_YAML
+    cfg = gu.CASES["sync_small"]
+    x0, Y, E0 = gu.real_graph(cfg)
+    src, dst = np.nonzero(E0)
+    gpath, ypath = os.path.join(tmp_path, "g.npz"), os.path.join(tmp_path, "train_Sync.yaml")
+    gdata.save_graph_npz(gpath, x0, Y, src, dst)
+    with open(ypath, "w") as fh:
+        fh.write(SYNC_YAML)
+    out = os.path.join(tmp_path, "cpts")
+    path = cli.main(["train", "--config", ypath, "--data", gpath, "--out", out, "--dataset", "toy"])
+    state = torch.load(path, weights_only=True)
+    assert state["dataset"] == "toy" and np.isfinite(state["best_val_nll"])
+    sdir = os.path.join(tmp_path, "samples")
+    cli.main(["sample", "--model_path", path, "--data", gpath, "--num_samples", "2", "--out", sdir])
+    for k in range(2):
+        g = gdata.load_graph_npz(os.path.join(sdir, f"sample_{k}.npz"))
+        assert g["num_nodes"] == cfg["N"] and g["src"].numel() % 2 == 0

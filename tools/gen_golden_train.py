@@ -139,8 +139,43 @@ def run_case(name, diffusion):
     print(f"{name}: wrote {path} ({os.path.getsize(path) / 1e3:.0f} kB) losses={losses} val={v}")
 
 
+def run_preprocess(name):
+    """The reference's data.py preprocess() on the synthetic real graph (a stand-in object with the three DGLGraph
+    members it touches: ndata, num_nodes(), edges()); `dgl` / `dgl.data` are empty stand-in modules for the imports."""
+    import importlib.util
+    import types
+    cfg = gu.CASES[name]
+    dgl = sys.modules.get("dgl") or types.ModuleType("dgl")
+    dd = types.ModuleType("dgl.data")
+    for cls in ("AmazonCoBuyPhotoDataset", "AmazonCoBuyComputerDataset", "CoraGraphDataset"):
+        setattr(dd, cls, object)
+    dgl.data = dd
+    sys.modules["dgl"], sys.modules["dgl.data"] = dgl, dd
+    spec = importlib.util.spec_from_file_location("gmref_data", os.path.join(gg.REF, "data.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    x0, Y, E0 = gu.real_graph(cfg)
+    src, dst = np.nonzero(E0)
+
+    class G:
+        ndata = {"feat": torch.from_numpy(x0).float(), "label": torch.from_numpy(Y)}
+
+        def num_nodes(self):
+            return cfg["N"]
+
+        def edges(self):
+            return torch.from_numpy(src), torch.from_numpy(dst)
+
+    X3, Yo, E1h, Xm, Ym, Em, XcY = mod.preprocess(G())
+    path = os.path.join(gu.GOLDEN_DIR, f"preprocess_{name}.npz")
+    np.savez_compressed(path, X_marginal=Xm.numpy(), Y_marginal=Ym.numpy(), E_marginal=Em.numpy(),
+                        X_cond_Y_marginals=XcY.numpy(), X_one_hot_sum=X3.sum((1,)).numpy(), E_ones=E1h[:, :, 1].sum().numpy())
+    print(f"{name}: wrote {path}")
+
+
 def main():
     gnn, diffusion = gg.load_reference()
+    run_preprocess("sync_small")
     for name in (sys.argv[1:] or gu.TRAIN_CASES):
         run_case(name, diffusion)
 
