@@ -20,7 +20,7 @@ EXPORTS = [
     "gm_x_from_onehot", "gm_prior_Y", "gm_prior_X", "gm_prior_E",
     "gm_noise_E", "gm_noise_X", "gm_bitmap_from_onehot_f32", "gm_x_from_onehot3d",
     "gm_gemm_workspace_bytes", "gm_gemm", "gm_colsum_workspace_bytes", "gm_colsum", "gm_layernorm_fwd",
-    "gm_layernorm_bwd_workspace_bytes", "gm_layernorm_bwd", "gm_spmm_mean_bwd", "gm_embedding_bwd",
+    "gm_layernorm_bwd_workspace_bytes", "gm_layernorm_bwd", "gm_spmm_mean_bwd", "gm_embedding_bwd_workspace_bytes", "gm_embedding_bwd",
     "gm_hadamard_gather_bwd", "gm_softmax_ce2_workspace_bytes", "gm_softmax_ce2",
     "gm_relu_bwd", "gm_dropout", "gm_embedding_fwd", "gm_denoise_match2", "gm_bitmap_lookup",
 ]
@@ -54,7 +54,7 @@ def load():
         lib.gm_last_error.restype = C.c_char_p
         lib.gm_version.restype = C.c_int
         for name in ("gm_gemm_workspace_bytes", "gm_colsum_workspace_bytes", "gm_layernorm_bwd_workspace_bytes",
-                     "gm_softmax_ce2_workspace_bytes"):
+                     "gm_softmax_ce2_workspace_bytes", "gm_embedding_bwd_workspace_bytes"):
             getattr(lib, name).restype = C.c_int64
         _lib = lib
     return _lib

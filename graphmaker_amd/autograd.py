@@ -182,7 +182,9 @@ class _Embedding(torch.autograd.Function):
         g = _c(g)
         Cn, w = ctx.shape
         dW = torch.empty((Cn, w), dtype=torch.float32, device=g.device)
-        L.call("gm_embedding_bwd", I64(idx32.numel()), I32(Cn), I32(w), ptr(idx32), ptr(g), I64(w), ptr(dW), I64(w), stream_ptr())
+        ws = _scratch(L.load().gm_embedding_bwd_workspace_bytes(I64(idx32.numel()), I32(Cn), I32(w)), g.device)
+        L.call("gm_embedding_bwd", I64(idx32.numel()), I32(Cn), I32(w), ptr(idx32), ptr(g), I64(w), ptr(dW), I64(w), ptr(ws),
+               I64(ws.numel()), stream_ptr())
         return dW, None
 
 

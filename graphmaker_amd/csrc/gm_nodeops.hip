@@ -11,7 +11,9 @@ namespace gm {
 // (chunk c = t + k*TPR, so one neighbour row is read as contiguous 16-byte pieces across the group) and walks the
 // row's neighbours in ascending order, acc = fmaf(H[j], 1/deg, acc) -- the order the oracle uses.
 // Neighbour ids are read 4 at a time so 4 independent row gathers are in flight per thread.
-template <int CH>
+// TRANSPOSED = true is the backward of the same operator for a symmetric adjacency: the weight of neighbour j is
+// 1/deg(j) instead of 1/deg(i)  ((D^-1 A)^T G, model/gnn.py:60-61 under autograd).
+template <int CH, bool TRANSPOSED = false>
 __global__ void __launch_bounds__(256)
 k_spmm_mean(int64_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
             const float* __restrict__ H, int64_t ldh, int nchunks, int tpr, float* __restrict__ out, int64_t ldo) {
@@ -25,12 +27,15 @@ k_spmm_mean(int64_t n, const int32_t* __restrict__ rowptr, const int32_t* __rest
 #pragma unroll
     for (int k = 0; k < CH; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (e > b) {
-        const float inv = 1.0f / (float)(e - b);
+        const float inv_row = 1.0f / (float)(e - b);
         int p = b;
         for (; p + 4 <= e; p += 4) {
             int j[4];
+            float w[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) j[q] = colidx[p + q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[q] = TRANSPOSED ? 1.0f / (float)(rowptr[j[q] + 1] - rowptr[j[q]]) : inv_row;
             float4 v[4][CH];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -44,14 +49,15 @@ k_spmm_mean(int64_t n, const int32_t* __restrict__ rowptr, const int32_t* __rest
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int k = 0; k < CH; ++k) {
-                    acc[k].x = __builtin_fmaf(v[q][k].x, inv, acc[k].x);
-                    acc[k].y = __builtin_fmaf(v[q][k].y, inv, acc[k].y);
-                    acc[k].z = __builtin_fmaf(v[q][k].z, inv, acc[k].z);
-                    acc[k].w = __builtin_fmaf(v[q][k].w, inv, acc[k].w);
+                    acc[k].x = __builtin_fmaf(v[q][k].x, w[q], acc[k].x);
+                    acc[k].y = __builtin_fmaf(v[q][k].y, w[q], acc[k].y);
+                    acc[k].z = __builtin_fmaf(v[q][k].z, w[q], acc[k].z);
+                    acc[k].w = __builtin_fmaf(v[q][k].w, w[q], acc[k].w);
                 }
         }
         for (; p < e; ++p) {
             const int j = colidx[p];
+            const float inv = TRANSPOSED ? 1.0f / (float)(rowptr[j + 1] - rowptr[j]) : inv_row;
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
                 const int c = t + k * tpr;
@@ -73,14 +79,19 @@ k_spmm_mean(int64_t n, const int32_t* __restrict__ rowptr, const int32_t* __rest
 }
 
 // scalar fallback for widths / strides that are not 16-byte friendly
+template <bool TRANSPOSED = false>
 __global__ void k_spmm_mean_scalar(int64_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
                                    const float* __restrict__ H, int64_t ldh, int64_t d, float* __restrict__ out, int64_t ldo) {
     const int64_t i = blockIdx.x;
     const int b = rowptr[i], e = rowptr[i + 1];
-    const float inv = e > b ? 1.0f / (float)(e - b) : 0.0f;
+    const float inv_row = e > b ? 1.0f / (float)(e - b) : 0.0f;
     for (int64_t c = threadIdx.x; c < d; c += blockDim.x) {
         float acc = 0.0f;
-        for (int p = b; p < e; ++p) acc = __builtin_fmaf(H[(int64_t)colidx[p] * ldh + c], inv, acc);
+        for (int p = b; p < e; ++p) {
+            const int j = colidx[p];
+            const float inv = TRANSPOSED ? 1.0f / (float)(rowptr[j + 1] - rowptr[j]) : inv_row;
+            acc = __builtin_fmaf(H[(int64_t)j * ldh + c], inv, acc);
+        }
         out[i * ldo + c] = acc;
     }
 }
@@ -170,32 +181,41 @@ int launch_copy2d(int64_t n, int w, const float* src, int64_t lds_, float* dst, 
 
 using namespace gm;
 
-extern "C" int gm_spmm_mean(int64_t n, const int32_t* rowptr, const int32_t* colidx, const float* H, int64_t ldh, int64_t d,
-                            float* out, int64_t ldo, gm_stream_t stream) {
-    GM_REQUIRE(n > 0 && d > 0 && rowptr && H && out, "bad arguments");
-    GM_REQUIRE(ldh >= d && ldo >= d, "leading dimensions smaller than d");
-    hipStream_t s = as_stream(stream);
+template <bool TRANSPOSED>
+static int launch_spmm(int64_t n, const int32_t* rowptr, const int32_t* colidx, const float* H, int64_t ldh, int64_t d,
+                       float* out, int64_t ldo, hipStream_t s) {
     const bool vec = (d % 4 == 0) && (ldh % 4 == 0) && (ldo % 4 == 0) && aligned(H, 16) && aligned(out, 16);
-    if (!vec) {
-        hipLaunchKernelGGL(k_spmm_mean_scalar, dim3((unsigned)n), dim3(128), 0, s, n, rowptr, colidx, H, ldh, d, out, ldo);
-        GM_LAUNCH_CHECK();
-        return GM_OK;
-    }
     const int nchunks = (int)(d / 4);
     // threads per row: a power of two in [4,64]; CH chunks per thread covers the row
     int tpr = 4;
     while (tpr < 64 && tpr < nchunks) tpr <<= 1;
     const int ch = (nchunks + tpr - 1) / tpr;
+    if (!vec || ch > 4) {
+        hipLaunchKernelGGL((k_spmm_mean_scalar<TRANSPOSED>), dim3((unsigned)n), dim3(vec ? 256 : 128), 0, s, n, rowptr, colidx, H,
+                           ldh, d, out, ldo);
+        GM_LAUNCH_CHECK();
+        return GM_OK;
+    }
     const int rows_per_block = 256 / tpr;
     dim3 grid((unsigned)((n + rows_per_block - 1) / rows_per_block)), block(256);
-    if (ch == 1) hipLaunchKernelGGL(k_spmm_mean<1>, grid, block, 0, s, n, rowptr, colidx, H, ldh, nchunks, tpr, out, ldo);
-    else if (ch == 2) hipLaunchKernelGGL(k_spmm_mean<2>, grid, block, 0, s, n, rowptr, colidx, H, ldh, nchunks, tpr, out, ldo);
-    else if (ch <= 4) hipLaunchKernelGGL(k_spmm_mean<4>, grid, block, 0, s, n, rowptr, colidx, H, ldh, nchunks, tpr, out, ldo);
-    else {
-        hipLaunchKernelGGL(k_spmm_mean_scalar, dim3((unsigned)n), dim3(256), 0, s, n, rowptr, colidx, H, ldh, d, out, ldo);
-    }
+    if (ch == 1) hipLaunchKernelGGL((k_spmm_mean<1, TRANSPOSED>), grid, block, 0, s, n, rowptr, colidx, H, ldh, nchunks, tpr, out, ldo);
+    else if (ch == 2) hipLaunchKernelGGL((k_spmm_mean<2, TRANSPOSED>), grid, block, 0, s, n, rowptr, colidx, H, ldh, nchunks, tpr, out, ldo);
+    else hipLaunchKernelGGL((k_spmm_mean<4, TRANSPOSED>), grid, block, 0, s, n, rowptr, colidx, H, ldh, nchunks, tpr, out, ldo);
     GM_LAUNCH_CHECK();
     return GM_OK;
+}
+
+extern "C" int gm_spmm_mean(int64_t n, const int32_t* rowptr, const int32_t* colidx, const float* H, int64_t ldh, int64_t d,
+                            float* out, int64_t ldo, gm_stream_t stream) {
+    GM_REQUIRE(n > 0 && d > 0 && rowptr && H && out, "bad arguments");
+    GM_REQUIRE(ldh >= d && ldo >= d, "leading dimensions smaller than d");
+    return launch_spmm<false>(n, rowptr, colidx, H, ldh, d, out, ldo, as_stream(stream));
+}
+
+extern "C" int gm_spmm_mean_bwd(int64_t n, const int32_t* rowptr, const int32_t* colidx, const float* G, int64_t ldg, int64_t d,
+                                float* out, int64_t ldo, gm_stream_t stream) {
+    GM_REQUIRE(n > 0 && d > 0 && rowptr && G && out && ldg >= d && ldo >= d, "bad arguments");
+    return launch_spmm<true>(n, rowptr, colidx, G, ldg, d, out, ldo, as_stream(stream));
 }
 
 extern "C" int gm_layernorm(int64_t M, int64_t N, float* X, int64_t ldx, const float* gamma, const float* beta, float eps,

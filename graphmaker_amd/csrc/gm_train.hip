@@ -165,6 +165,30 @@ __global__ void k_splitk_reduce(int S, int64_t M, int64_t N, const float* __rest
     C[m * ldc + n] = finish(acc, bias, mask, ldmask, relu, m, n);
 }
 
+// the same sum for many partials: 16 outputs x 16 partial lanes per block; lane l adds partials l, l+16, ... in ascending
+// order, then the 16 lane sums are added in ascending lane order (fixed order, independent of the launch)
+__global__ void __launch_bounds__(256)
+k_splitk_reduce_wide(int S, int64_t M, int64_t N, const float* __restrict__ part, const float* __restrict__ bias,
+                     const float* __restrict__ mask, int64_t ldmask, int relu, float* __restrict__ C, int64_t ldc) {
+    __shared__ float red[16][17];
+    const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int64_t g = (int64_t)blockIdx.x * 16 + o;
+    float acc = 0.0f;
+    if (g < M * N)
+        for (int s = sl; s < S; s += 16) acc = acc + part[(int64_t)s * M * N + g];
+    red[sl][o] = acc;
+    __syncthreads();
+    if (sl == 0 && g < M * N) {
+        float v = red[0][o];
+#pragma unroll
+        for (int l = 1; l < 16; ++l) v = v + red[l][o];
+        const int64_t m = g / N, n = g % N;
+        C[m * ldc + n] = finish(v, bias, mask, ldmask, relu, m, n);
+    }
+}
+static int launch_reduce(int S, int64_t M, int64_t N, const float* part, const float* bias, const float* mask, int64_t ldmask,
+                         int relu, float* C, int64_t ldc, hipStream_t s);
+
 // ---- column sums: part[blk][n] = sum over the block's rows (ascending, 4 row lanes combined in order)
 constexpr int CS_ROWS = 64;   // rows per block
 __global__ void __launch_bounds__(256)
@@ -276,48 +300,24 @@ k_layernorm_bwd(int64_t M, int64_t N, const float* __restrict__ dY, int64_t lddy
     }
 }
 
-// ---- (D^-1 A)^T G: one block row of threads per output node, neighbour weight 1/deg(neighbour)
+// ---- d emb.weight[c][col] = sum_{v : idx[v] == c} G[v][col]: blocks of EB_ROWS rows write partial sums (rows ascending per
+// wave, 4 waves combined in order), the chunks are then added in ascending order
+constexpr int EB_ROWS = 512;
 __global__ void __launch_bounds__(256)
-k_spmm_mean_bwd(int64_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, const float* __restrict__ G,
-                int64_t ldg, int64_t d, float* __restrict__ out, int64_t ldo) {
-    // 64 threads per node, 4 nodes per block; each thread walks columns lane, lane+64, ...
-    const int lane = threadIdx.x & 63;
-    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (j >= n) return;
-    const int b = rowptr[j], e = rowptr[j + 1];
-    for (int64_t c0 = 0; c0 < d; c0 += 256) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int p = b; p < e; ++p) {
-            const int i = colidx[p];
-            const float inv = 1.0f / (float)(rowptr[i + 1] - rowptr[i]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int64_t c = c0 + lane + 64 * q;
-                if (c < d) acc[q] = __builtin_fmaf(G[(int64_t)i * ldg + c], inv, acc[q]);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int64_t c = c0 + lane + 64 * q;
-            if (c < d) out[j * ldo + c] = acc[q];
-        }
-    }
-}
-
-// ---- d emb.weight[c][col] = sum_{v : idx[v] == c} G[v][col], rows visited in ascending order per wave, 4 waves combined
-__global__ void __launch_bounds__(256)
-k_embedding_bwd(int64_t n, int w, const int32_t* __restrict__ idx, const float* __restrict__ G, int64_t ldg,
-                float* __restrict__ dW, int64_t ldw) {
+k_embedding_bwd(int64_t n, int C, int w, const int32_t* __restrict__ idx, const float* __restrict__ G, int64_t ldg,
+                float* __restrict__ part) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int c = blockIdx.x;
     const int col = blockIdx.y * 64 + lane;
+    const int64_t r0 = (int64_t)blockIdx.z * EB_ROWS;
     float acc = 0.0f;
-    for (int64_t v = wv; v < n; v += 4)
+    for (int64_t v = r0 + wv; v < r0 + EB_ROWS && v < n; v += 4)
         if (idx[v] == c && col < w) acc = acc + G[v * ldg + col];
     red[wv][lane] = acc;
     __syncthreads();
-    if (wv == 0 && col < w) dW[(int64_t)c * ldw + col] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    if (wv == 0 && col < w)
+        part[((int64_t)blockIdx.z * C + c) * w + col] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
 }
 
 // ---- d h[i] = sum over the batch entries that touch node i (grouped by node, ascending position in cat[src, dst]) of
@@ -444,6 +444,18 @@ __global__ void k_bitmap_lookup(int64_t B, const int64_t* __restrict__ i, const 
     out[b] = (bits[i[b] * wpr + (j[b] >> 5)] >> (j[b] & 31)) & 1u;
 }
 
+static int launch_reduce(int S, int64_t M, int64_t N, const float* part, const float* bias, const float* mask, int64_t ldmask,
+                         int relu, float* C, int64_t ldc, hipStream_t s) {
+    if (S <= 8)
+        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, s, S, M, N, part, bias, mask,
+                           ldmask, relu, C, ldc);
+    else
+        hipLaunchKernelGGL(k_splitk_reduce_wide, dim3((unsigned)((M * N + 15) / 16)), dim3(256), 0, s, S, M, N, part, bias, mask,
+                           ldmask, relu, C, ldc);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
 static inline int pick_splits(int64_t M, int64_t N, int64_t K) {
     const int64_t tiles = ((M + TBM - 1) / TBM) * ((N + TBN - 1) / TBN);
     int64_t s = 512 / tiles;
@@ -493,9 +505,7 @@ extern "C" int gm_gemm(int a_red, int b_red, int64_t M, int64_t N, int64_t K, co
 #undef GM_LAUNCH_G
     GM_LAUNCH_CHECK();
     if (splits > 1) {
-        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, s, splits, M, N,
-                           static_cast<const float*>(workspace), bias, mask, ldmask, relu, C, ldc);
-        GM_LAUNCH_CHECK();
+        return launch_reduce(splits, M, N, static_cast<const float*>(workspace), bias, mask, ldmask, relu, C, ldc, s);
     }
     return GM_OK;
 }
@@ -512,10 +522,7 @@ extern "C" int gm_colsum(int64_t M, int64_t N, const float* X, int64_t ldx, floa
     float* part = static_cast<float*>(workspace);
     hipLaunchKernelGGL(k_colsum_partial, dim3((unsigned)((N + 63) / 64), (unsigned)nblk), dim3(256), 0, s, M, N, X, ldx, part);
     GM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, (int)nblk, (int64_t)1, N, part,
-                       (const float*)nullptr, (const float*)nullptr, (int64_t)0, 0, out, N);
-    GM_LAUNCH_CHECK();
-    return GM_OK;
+    return launch_reduce((int)nblk, 1, N, part, nullptr, nullptr, 0, 0, out, N, s);
 }
 
 extern "C" int gm_layernorm_fwd(int64_t M, int64_t N, const float* X, int64_t ldx, const float* gamma, const float* beta,
@@ -545,28 +552,26 @@ extern "C" int gm_layernorm_bwd(int64_t M, int64_t N, const float* dY, int64_t l
     hipLaunchKernelGGL(k_layernorm_bwd, dim3((unsigned)nblk), dim3(256), (size_t)(8 * N * 4), s, M, N, dY, lddy, X, ldx, mean,
                        rstd, gamma, relu_mask, dX, lddx, part);
     GM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((2 * N + 255) / 256)), dim3(256), 0, s, (int)nblk, (int64_t)1, 2 * N,
-                       part, (const float*)nullptr, (const float*)nullptr, (int64_t)0, 0, dgamma, 2 * N);
-    GM_LAUNCH_CHECK();
-    return GM_OK;
+    return launch_reduce((int)nblk, 1, 2 * N, part, nullptr, nullptr, 0, 0, dgamma, 2 * N, s);
 }
 
-extern "C" int gm_spmm_mean_bwd(int64_t n, const int32_t* rowptr, const int32_t* colidx, const float* G, int64_t ldg, int64_t d,
-                                float* out, int64_t ldo, gm_stream_t stream) {
-    GM_REQUIRE(n > 0 && d > 0 && rowptr && G && out && ldg >= d && ldo >= d, "bad arguments");
-    hipLaunchKernelGGL(k_spmm_mean_bwd, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, as_stream(stream), n, rowptr, colidx, G, ldg,
-                       d, out, ldo);
-    GM_LAUNCH_CHECK();
-    return GM_OK;
+extern "C" int64_t gm_embedding_bwd_workspace_bytes(int64_t n, int C, int w) {
+    return ((n + EB_ROWS - 1) / EB_ROWS) * (int64_t)C * w * 4;
 }
 
 extern "C" int gm_embedding_bwd(int64_t n, int C, int w, const int32_t* idx, const float* G, int64_t ldg, float* dW, int64_t ldw,
-                                gm_stream_t stream) {
+                                void* workspace, int64_t workspace_bytes, gm_stream_t stream) {
     GM_REQUIRE(n > 0 && C > 0 && w > 0 && idx && G && dW && ldg >= w && ldw >= w, "bad arguments");
-    hipLaunchKernelGGL(k_embedding_bwd, dim3((unsigned)C, (unsigned)((w + 63) / 64)), dim3(256), 0, as_stream(stream), n, w, idx,
-                       G, ldg, dW, ldw);
+    const int64_t nchunk = (n + EB_ROWS - 1) / EB_ROWS;
+    GM_REQUIRE(workspace && workspace_bytes >= nchunk * C * w * 4, "gm_embedding_bwd needs %lld workspace bytes",
+               (long long)(nchunk * C * w * 4));
+    GM_REQUIRE(nchunk < 65536, "n too large");
+    hipStream_t s = as_stream(stream);
+    float* part = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(k_embedding_bwd, dim3((unsigned)C, (unsigned)((w + 63) / 64), (unsigned)nchunk), dim3(256), 0, s, n, C, w,
+                       idx, G, ldg, part);
     GM_LAUNCH_CHECK();
-    return GM_OK;
+    return launch_reduce((int)nchunk, C, w, part, nullptr, nullptr, 0, 0, dW, ldw, s);
 }
 
 extern "C" int gm_hadamard_gather_bwd(int64_t n, int64_t B, int64_t d, const int64_t* src, const int64_t* dst,
@@ -590,10 +595,7 @@ extern "C" int gm_softmax_ce2(int64_t total, const float* logits, const uint8_t*
     float* part = static_cast<float*>(workspace);
     hipLaunchKernelGGL(k_softmax_ce2, dim3(CE_BLOCKS), dim3(256), 0, s, total, logits, target, 1.0f / (float)total, part, dlogits);
     GM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_splitk_reduce, dim3(1), dim3(256), 0, s, CE_BLOCKS, (int64_t)1, (int64_t)1, part, (const float*)nullptr,
-                       (const float*)nullptr, (int64_t)0, 0, loss, (int64_t)1);
-    GM_LAUNCH_CHECK();
-    return GM_OK;
+    return launch_reduce(CE_BLOCKS, 1, 1, part, nullptr, nullptr, 0, 0, loss, 1, s);
 }
 
 extern "C" int gm_relu_bwd(int64_t total, const float* g, const float* y, float* out, gm_stream_t stream) {
@@ -630,10 +632,7 @@ extern "C" int gm_denoise_match2(int64_t total, const float* logits, const uint8
     hipLaunchKernelGGL(k_denoise_match2, dim3(CE_BLOCKS), dim3(256), 0, s, total, logits, z_t, z_0, Q_t, Q_bar_s, ntab,
                        1.0f / (2.0f * (float)total), part);
     GM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_splitk_reduce, dim3(1), dim3(256), 0, s, CE_BLOCKS, (int64_t)1, (int64_t)1, part, (const float*)nullptr,
-                       (const float*)nullptr, (int64_t)0, 0, out, (int64_t)1);
-    GM_LAUNCH_CHECK();
-    return GM_OK;
+    return launch_reduce(CE_BLOCKS, 1, 1, part, nullptr, nullptr, 0, 0, out, 1, s);
 }
 
 extern "C" int gm_bitmap_lookup(int64_t n, int64_t wpr, const uint32_t* bits, int64_t B, const int64_t* i, const int64_t* j,

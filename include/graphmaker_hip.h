@@ -187,8 +187,9 @@ int gm_layernorm_bwd(int64_t M, int64_t N, const float* dY, int64_t lddy, const 
 int gm_spmm_mean_bwd(int64_t n, const int32_t* rowptr, const int32_t* colidx, const float* G, int64_t ldg, int64_t d,
                      float* out, int64_t ldo, gm_stream_t stream);
 /* d emb_Y.weight (C, w) of the label embedding (model/gnn.py:155): dW[c] = sum_{v: idx[v]==c} G[v] */
+int64_t gm_embedding_bwd_workspace_bytes(int64_t n, int C, int w);
 int gm_embedding_bwd(int64_t n, int C, int w, const int32_t* idx, const float* G, int64_t ldg, float* dW, int64_t ldw,
-                     gm_stream_t stream);
+                     void* workspace, int64_t workspace_bytes, gm_stream_t stream);
 /* d h of z[b] = h[src[b]] * h[dst[b]] (model/gnn.py:246).  order (2B): stable sort permutation of cat[src, dst] by
  * node; segptr (n+1): start of each node's run in `order`.  No atomics: one wave per node walks its run in order. */
 int gm_hadamard_gather_bwd(int64_t n, int64_t B, int64_t d, const int64_t* src, const int64_t* dst,
