@@ -228,7 +228,8 @@ def main():
     traffic = None          # HBM bytes per launch of the pair kernel, from the committed PMC passes of this same command
     try:
         with open(os.path.join(ROOT, "profiles", "r1_pmc_summary.json")) as fh:
-            traffic = json.load(fh)["_derived"]["pair_kernel_hbm_traffic_bytes_per_launch"] if world == 1 else None
+            traffic = json.load(fh)["_derived"]["pair_kernel_hbm_traffic_bytes_per_launch"] \
+                if world == 1 and wl["name"] == "amazon_computer" else None
     except Exception:
         traffic = None
     if rank == 0:

@@ -23,6 +23,7 @@ EXPORTS = [
     "gm_layernorm_bwd_workspace_bytes", "gm_layernorm_bwd", "gm_spmm_mean_bwd", "gm_embedding_bwd_workspace_bytes", "gm_embedding_bwd",
     "gm_hadamard_gather_bwd", "gm_softmax_ce2_workspace_bytes", "gm_softmax_ce2",
     "gm_relu_bwd", "gm_dropout", "gm_embedding_fwd", "gm_denoise_match2", "gm_bitmap_lookup",
+    "gm_triangles_per_node", "gm_same_class_degree", "gm_bitmap_square", "gm_class_bitmaps", "gm_masked_degree",
 ]
 
 

@@ -220,6 +220,23 @@ int gm_denoise_match2(int64_t total, const float* logits, const uint8_t* z_t, co
 int gm_bitmap_lookup(int64_t n, int64_t wpr, const uint32_t* bits, int64_t B, const int64_t* i, const int64_t* j,
                      uint8_t* out, gm_stream_t stream);
 
+/* ---- integer statistics of a generated graph (eval_utils.py:19-74, 506-596) on bitmap + CSR; no self loops ----
+ * tri2[v] = sum_{u in N(v)} |N(v) & N(u)| = 2 * (triangles through v): get_triangle_count (:19-21) = sum(tri2) / 6,
+ * nx.clustering (:585) = tri2[v] / (deg(v) * (deg(v) - 1)) */
+int gm_triangles_per_node(int64_t n, int64_t wpr, const uint32_t* bits, const int32_t* rowptr, const int32_t* colidx,
+                          int64_t* tri2, gm_stream_t stream);
+/* out[v] = |{u in N(v): y[u] == y[v]}|  (linkx_homophily, eval_utils.py:52-59) */
+int gm_same_class_degree(int64_t n, const int32_t* rowptr, const int32_t* colidx, const int32_t* y, int32_t* out,
+                         gm_stream_t stream);
+/* pattern of A @ A (k_order_g, eval_utils.py:521-529): out[i] = OR_{j in N(i)} bits[j] (the diagonal is set where deg > 0) */
+int gm_bitmap_square(int64_t n, int64_t wpr, const uint32_t* bits, const int32_t* rowptr, const int32_t* colidx,
+                     uint32_t* out, gm_stream_t stream);
+/* out[c] = bitmap row of the nodes with label c (C rows of wpr words) */
+int gm_class_bitmaps(int64_t n, int64_t wpr, int C, const int32_t* y, uint32_t* out, gm_stream_t stream);
+/* deg[v] = popcount(bits[v]); same[v] = popcount(bits[v] & classrows[y[v]]) */
+int gm_masked_degree(int64_t n, int64_t wpr, const uint32_t* bits, const uint32_t* classrows, const int32_t* y,
+                     int32_t* deg, int32_t* same, gm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
