@@ -219,6 +219,15 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # a whole Sync sample (priors + all T reverse steps, free-running state) on all ranks, outside the timed steps
+    full_sample_ms = None
+    if not args.no_extras:
+        barrier()
+        t0 = time.perf_counter()
+        model.sample(seed=7, dense=False, plan=plan)
+        barrier()
+        full_sample_ms = (time.perf_counter() - t0) * 1e3
+
     P = n * (n - 1) // 2
     ms_per_step = elapsed / args.steps * 1e3
     pair_ms = phases.get("pair", float("nan"))                  # this rank's share of the pair matrix
@@ -254,10 +263,8 @@ def main():
         }
         if world == 1 and not args.no_extras:
             res["roofline_secondary"] = secondary_rooflines(wl, model, bits, dev)
-            t0 = time.perf_counter()
-            model.sample(seed=7, dense=False)
-            torch.cuda.synchronize()
-            res["full_sample_ms"] = (time.perf_counter() - t0) * 1e3     # priors + all T steps, one GPU, free-running
+        if full_sample_ms is not None:
+            res["full_sample_ms"] = full_sample_ms
         if not args.no_cpu_baseline and world == 1:
             try:
                 res["cpu_baseline"] = cpu_baseline(wl, model, (x, oh, Y32, bits), budget_rows=args.cpu_rows,
