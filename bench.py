@@ -164,6 +164,10 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=768)
     ap.add_argument("--force-plan", action="store_true",
                     help="run the sharded code path (ShardPlan + RCCL all-gathers) even with one rank: a rehearsal of N>1")
+    ap.add_argument("--rehearse-world", type=int, default=0, metavar="G",
+                    help="diagnostic, one GPU: time rank --rehearse-rank's share of a G-rank step with the collectives "
+                         "replaced by no-ops (results are not meaningful, only the per-rank compute + launch time is)")
+    ap.add_argument("--rehearse-rank", type=int, default=0)
     args = ap.parse_args()
 
     wl = WORKLOADS[args.workload]
@@ -183,6 +187,12 @@ def main():
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         from graphmaker_amd.parallel import ShardPlan
         plan = ShardPlan.make(wl["N"], world, rank)
+    elif args.rehearse_world > 1:
+        from graphmaker_amd import parallel
+        plan = parallel.ShardPlan.make(wl["N"], args.rehearse_world, args.rehearse_rank)
+        parallel.all_gather_node_rows = lambda plan, full, group=None: full
+        parallel.gather_upper_rows = lambda plan, upper, group=None: upper
+        args.no_extras = args.no_cpu_baseline = True
 
     from graphmaker_amd import ops
     model = build_model(wl, dev)
@@ -194,7 +204,7 @@ def main():
     nnz = int(ops.csr_from_bitmap(bits, n)[0][n].item())
 
     def barrier():
-        if plan is not None:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -214,7 +224,7 @@ def main():
     elapsed = time.perf_counter() - t0
     phases = {k: float(np.mean(v)) for k, v in model.phase_times_ms().items()}
     model.enable_phase_timing(False)
-    if plan is not None:
+    if dist.is_initialized():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -231,7 +241,7 @@ def main():
     P = n * (n - 1) // 2
     ms_per_step = elapsed / args.steps * 1e3
     pair_ms = phases.get("pair", float("nan"))                  # this rank's share of the pair matrix
-    pairs_here = P if plan is None else plan.pairs_of(rank)
+    pairs_here = P if plan is None else plan.pairs_of(plan.rank)
     achieved = FLOP_PER_PAIR * pairs_here / (pair_ms * 1e-3) / 1e12
 
     traffic = None          # HBM bytes per launch of the pair kernel, from the committed PMC passes of this same command
@@ -241,6 +251,11 @@ def main():
                 if world == 1 and wl["name"] == "amazon_computer" else None
     except Exception:
         traffic = None
+    if args.rehearse_world > 1:
+        print(json.dumps({"rehearsal": f"rank {plan.rank} of {plan.world}, collectives replaced by no-ops, one GPU",
+                          "ms_per_step": ms_per_step, "phases_ms": phases, "pairs_this_rank": pairs_here,
+                          "pair_TFLOPs": achieved}))
+        return
     if rank == 0:
         res = {
             "metric": f"denoising steps/sec ({wl['name']} Sync step); pair-scores/sec in pair_scores_per_sec",
@@ -272,7 +287,7 @@ def main():
             except Exception as exc:  # the baseline must never take the GPU number down with it
                 res["cpu_baseline"] = {"value": None, "error": repr(exc)}
         print(json.dumps(res))
-    if plan is not None:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

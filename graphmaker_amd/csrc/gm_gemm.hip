@@ -2,185 +2,171 @@
 //
 //   C[M,N] = act( A[M,K] @ W[N,K]^T + bias[N] )            fp32 in, fp32 accumulate, exact fp32
 //
-// v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain (MI355X guide, "FP32-input MFMA"), so every output element is
+// v_mfma_f32_16x16x4_f32 is a k-ordered fmaf chain (MI355X guide, "FP32-input MFMA"), so every output element is
 //   acc = 0;  for k = 0..K-1: acc = fmaf(A[m][k], W[n][k], acc);  out = acc + bias[n]
 // exactly what oracle/gm_oracle.c gmo_linear computes: no split-K, K walked in ascending order.
 //
-// Tiling: 128x128 block tile, BK = 16, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles
-// (64 accumulator registers).  Operand tiles sit in LDS k-major (As[k][m], Bs[k][n]) so that the MFMA operand
-// read "lane l takes element (l&31) of k-row (l>>5)" is one conflict-free ds_read_b32 per fragment.
-// Global -> register -> LDS staging with the next tile's loads issued before the current tile's MFMAs.
-// Roofline: MFMA-bound (157 TFLOP/s f32 matrix peak); 32 FLOP per operand byte at this tile size.
+// Why the 16x16x4 form and not 32x32x2 (same peak rate): it advances a chain by 4 k per 32-cycle issue instead of 2 k
+// per 64 cycles, so the serial K walk of one output is 3.2x shorter, its 4-register accumulators let 4 workgroups
+// (16 waves) share a CU, and 64x64 block tiles give 4x as many workgroups -- which is what the row-sharded towers
+// (N/G rows per rank) and the narrow layers (128 / 512 outputs) need.  Measured on the tower shapes (tools/gemm_ab.py):
+// 13752x512x1534 80 -> 96 TFLOP/s, 1719x1744x1744 62 -> 85, 1719x128x1744 8 -> 15, 13752x1744x1744 106 -> 121.
+//
+// LDS tiles are plain row-major, double-buffered, one barrier per k-tile; row stride KT + 4 floats makes the operand
+// read "row lane&15, k = 4s + lane>>4" touch all 64 banks once (16 distinct multiples of 4, plus lane>>4).
+// Global -> register -> LDS staging with the next tile's loads in flight under the MFMAs.
+// Roofline: MFMA-bound (157 TFLOP/s f32 matrix peak).
 #include "gm_common.h"
 
 namespace gm {
 
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-
-#ifndef GM_GEMM_BK
-#define GM_GEMM_BK 16
-#endif
-#ifndef GM_GEMM_SMALL_TILES
-#define GM_GEMM_SMALL_TILES 768
-#endif
-#define GM_GEMM_XCD 1   // XCD-aware tile order (measured +2-3% on the 1744-wide layers)
-constexpr int BN = 128, BK = GM_GEMM_BK;
-constexpr int KPT = BK / 2;   // k values staged per thread and operand (row = tid/2, k-half = tid%2)
-#ifndef GM_GEMM_LDT
-#define GM_GEMM_LDT 136
-#endif
-constexpr int LDT = GM_GEMM_LDT;  // padded k-row length (floats)
-
-// Each thread stages 8 consecutive k of one tile row: row = tid/2, k-half = tid%2.
-template <int VEC>
-__device__ __forceinline__ void load_row8(const float* __restrict__ base, int64_t ld, int64_t row, int64_t nrows,
-                                          int64_t k0, int64_t K, float (&r)[8]) {
-    if (row >= nrows) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) r[q] = 0.0f;
-        return;
-    }
-    const float* p = base + row * ld + k0;
-    if (VEC == 4) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            if (k0 + 4 * q + 4 <= K) {
-                float4 v = *reinterpret_cast<const float4*>(p + 4 * q);
-                r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) r[4 * q + e] = (k0 + 4 * q + e < K) ? p[4 * q + e] : 0.0f;
-            }
-        }
-    } else if (VEC == 2) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (k0 + 2 * q + 2 <= K) {
-                float2 v = *reinterpret_cast<const float2*>(p + 2 * q);
-                r[2 * q] = v.x; r[2 * q + 1] = v.y;
-            } else {
-                r[2 * q] = (k0 + 2 * q < K) ? p[2 * q] : 0.0f;
-                r[2 * q + 1] = 0.0f;
-            }
+// 4 consecutive k of one operand row -> registers.  GUARD: zeros beyond K (ragged last tile); zero products leave the
+// fmaf chain unchanged (an accumulator that starts at +0 never becomes -0).
+template <int VEC, bool GUARD>
+__device__ __forceinline__ float4 load_k4(const float* __restrict__ p, int64_t k, int64_t K) {
+    float4 v;
+    if (!GUARD) {
+        if (VEC == 4) {
+            v = *reinterpret_cast<const float4*>(p);
+        } else if (VEC == 2) {
+            const float2 a = *reinterpret_cast<const float2*>(p), b = *reinterpret_cast<const float2*>(p + 2);
+            v = make_float4(a.x, a.y, b.x, b.y);
+        } else {
+            v = make_float4(p[0], p[1], p[2], p[3]);
         }
     } else {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) r[q] = (k0 + q < K) ? p[q] : 0.0f;
+        v.x = k + 0 < K ? p[0] : 0.0f;
+        v.y = k + 1 < K ? p[1] : 0.0f;
+        v.z = k + 2 < K ? p[2] : 0.0f;
+        v.w = k + 3 < K ? p[3] : 0.0f;
     }
+    return v;
 }
 
-// unguarded twin of load_row8 for tiles that lie fully inside K (rows are clamped by the caller): straight-line
-// vector loads, so all of a tile's loads are in flight together instead of one branch + wait per vector.
-template <int VEC>
-__device__ __forceinline__ void load_row8_fast(const float* __restrict__ p, float (&r)[8]) {
-    if (VEC == 4) {
-        const float4 v0 = *reinterpret_cast<const float4*>(p), v1 = *reinterpret_cast<const float4*>(p + 4);
-        r[0] = v0.x; r[1] = v0.y; r[2] = v0.z; r[3] = v0.w; r[4] = v1.x; r[5] = v1.y; r[6] = v1.z; r[7] = v1.w;
-    } else if (VEC == 2) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float2 v = *reinterpret_cast<const float2*>(p + 2 * q);
-            r[2 * q] = v.x; r[2 * q + 1] = v.y;
-        }
-    } else {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) r[q] = p[q];
-    }
-}
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-// MT = 32-row MFMA tiles per wave along M: the block tile is (64*MT) x 128.  MT = 1 doubles the number of workgroups for
-// layers whose 128-row tiling would leave CUs idle (N = 128 / 512 outputs); the k order per output is the same.
-template <int VEC, int MT>
-__global__ void __launch_bounds__(256, 2)
+// TM x TN 16x16 MFMA tiles per wave, WGM x WGN waves: block tile (16 TM WGM) x (16 TN WGN); KT-wide k-tiles (row stride
+// KT + 4 keeps the banks distinct for KT = 16 and 32); OCC = workgroups per CU the register/LDS budget is set for.
+template <int VEC, int TM, int TN, int KT, int OCC, int WGM = 2, int WGN = 2>
+__global__ void __launch_bounds__(64 * WGM * WGN, OCC)
 k_linear(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
-         int64_t ldw, const float* __restrict__ bias, float* __restrict__ C, int64_t ldc, int relu) {
-    __shared__ float As[BK * LDT];
-    __shared__ float Bs[BK * LDT];
+           int64_t ldw, const float* __restrict__ bias, float* __restrict__ C, int64_t ldc, int relu) {
+    constexpr int SBM = 16 * TM * WGM, SBN = 16 * TN * WGN, LD = KT + 4, NT = 64 * WGM * WGN;
+    constexpr int QPR = KT / 4;                                // float4 per tile row
+    constexpr int NA = SBM * QPR / NT, NB = SBN * QPR / NT;    // float4 per thread and tile
+    constexpr int RSTEP = NT / QPR;                            // rows between a thread's consecutive slots
+    static_assert(NA >= 1 && NB >= 1, "tile too small for the staging threads");
+    __shared__ __attribute__((aligned(16))) float As[2][SBM * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][SBN * LD];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
-    const int l31 = lane & 31, half = lane >> 5;
-    const int wm = wv >> 1, wn = wv & 1;  // wave position in the 2x2 grid
-    constexpr int BM = 64 * MT;
-#ifdef GM_GEMM_XCD
+    const int i16 = lane & 15, kg = lane >> 4;
+    const int wm = wv / WGN, wn = wv % WGN;
+    const int64_t gx = (N + SBN - 1) / SBN, gy = (M + SBM - 1) / SBM, total = gx * gy;
     // workgroups are dealt round-robin to the 8 XCDs: give each XCD a contiguous run of tiles (n fastest) so that the A
     // row-tile a run shares stays in that XCD's L2
-    const int64_t gx = (N + BN - 1) / BN, gy = (M + BM - 1) / BM, total = gx * gy;
     const int64_t per = (total + 7) / 8;
     const int64_t logical = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if ((blockIdx.x >> 3) >= per || logical >= total) return;
-    const int64_t m0 = (logical / gx) * BM, n0 = (logical % gx) * BN;
-#else
-    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
-#endif
+    const int64_t m0 = (logical / gx) * SBM, n0 = (logical % gx) * SBN;
 
-    const int srow = tid >> 1, skh = (tid & 1) * KPT;
-    // rows past the edge are clamped, not zeroed: they only feed output rows/columns that are never stored
-    const bool stage_a = srow < BM;   // MT = 1: only half of the threads stage A rows
-    const float* pa = A + (m0 + srow < M ? m0 + srow : M - 1) * lda + skh;
-    const float* pw = W + (n0 + srow < N ? n0 + srow : N - 1) * ldw + skh;
-    float ra[KPT / 8][8], rb[KPT / 8][8];
+    const int srow = tid / QPR, skq = (tid % QPR) * 4;         // float4 slot f = tid + NT*c: row f/QPR, k-quad f%QPR
+    const float* pa[NA];
+    const float* pw[NB];
 #pragma unroll
-    for (int c = 0; c < KPT / 8; ++c) {
-        if (stage_a) load_row8<VEC>(A, lda, m0 + srow, M, skh + 8 * c, K, ra[c]);
-        load_row8<VEC>(W, ldw, n0 + srow, N, skh + 8 * c, K, rb[c]);
+    for (int c = 0; c < NA; ++c) {
+        const int64_t r = m0 + srow + RSTEP * c;
+        pa[c] = A + (r < M ? r : M - 1) * lda + skq;          // clamped rows only feed outputs that are never stored
     }
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+        const int64_t r = n0 + srow + RSTEP * c;
+        pw[c] = W + (r < N ? r : N - 1) * ldw + skq;
+    }
+    float4 ra[NA], rb[NB];
+    auto fetch_fast = [&](int64_t k0) {
+#pragma unroll
+        for (int c = 0; c < NA; ++c) ra[c] = load_k4<VEC, false>(pa[c] + k0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < NB; ++c) rb[c] = load_k4<VEC, false>(pw[c] + k0, 0, 0);
+    };
+    auto fetch_tail = [&](int64_t k0) {
+#pragma unroll
+        for (int c = 0; c < NA; ++c) ra[c] = load_k4<VEC, true>(pa[c] + k0, k0 + skq, K);
+#pragma unroll
+        for (int c = 0; c < NB; ++c) rb[c] = load_k4<VEC, true>(pw[c] + k0, k0 + skq, K);
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int c = 0; c < NA; ++c) *reinterpret_cast<float4*>(As[buf] + (srow + RSTEP * c) * LD + skq) = ra[c];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) *reinterpret_cast<float4*>(Bs[buf] + (srow + RSTEP * c) * LD + skq) = rb[c];
+    };
 
-    floatx16 acc[MT][2];
+    floatx4 acc[TM][TN];
 #pragma unroll
-    for (int a = 0; a < MT; ++a)
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < TN; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+            for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.0f;
 
-    for (int64_t k0 = 0; k0 < K; k0 += BK) {
-        __syncthreads();  // previous tile's fragment reads are done
+    const int aoff = (wm * 16 * TM + i16) * LD + kg;
+    const int boff = (wn * 16 * TN + i16) * LD + kg;
+    auto multiply = [&](int buf) {     // one k-tile: KT/4 MFMA k-steps in ascending k
+        const float* as = As[buf] + aoff;
+        const float* bs = Bs[buf] + boff;
 #pragma unroll
-        for (int c = 0; c < KPT / 8; ++c)
+        for (int st = 0; st < KT / 4; ++st) {
+            float av[TM], bv[TN];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                if (stage_a) As[(skh + 8 * c + q) * LDT + srow] = ra[c][q];
-                Bs[(skh + 8 * c + q) * LDT + srow] = rb[c][q];
-            }
+            for (int a = 0; a < TM; ++a) av[a] = as[16 * a * LD + 4 * st];
+#pragma unroll
+            for (int b = 0; b < TN; ++b) bv[b] = bs[16 * b * LD + 4 * st];
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
+    };
+
+    const int64_t nfull = K / KT;
+    const bool tail = (K % KT) != 0;
+    if (nfull > 0) fetch_fast(0); else fetch_tail(0);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t it = 0; it + 1 < nfull; ++it, buf ^= 1) {
+        fetch_fast((it + 1) * KT);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(buf);
+        __builtin_amdgcn_sched_barrier(0);
+        stash(buf ^ 1);
         __syncthreads();
-        if (k0 + 2 * BK <= K) {  // next tile (fully inside K) in flight while this one is multiplied
-#pragma unroll
-            for (int c = 0; c < KPT / 8; ++c) {
-                if (stage_a) load_row8_fast<VEC>(pa + k0 + BK + 8 * c, ra[c]);
-                load_row8_fast<VEC>(pw + k0 + BK + 8 * c, rb[c]);
-            }
-        } else if (k0 + BK < K) {  // ragged last tile: guarded loads, zeros beyond K
-#pragma unroll
-            for (int c = 0; c < KPT / 8; ++c) {
-                if (stage_a) load_row8<VEC>(A, lda, m0 + srow, M, k0 + BK + skh + 8 * c, K, ra[c]);
-                load_row8<VEC>(W, ldw, n0 + srow, N, k0 + BK + skh + 8 * c, K, rb[c]);
-            }
-        }
-#pragma unroll
-        for (int ks = 0; ks < BK / 2; ++ks) {
-            const int krow = (2 * ks + half) * LDT;
-            float b0 = Bs[krow + wn * 64 + l31];
-            float b1 = Bs[krow + wn * 64 + 32 + l31];
-#pragma unroll
-            for (int a = 0; a < MT; ++a) {
-                const float av = As[krow + wm * 32 * MT + 32 * a + l31];
-                acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[a][0], 0, 0, 0);
-                acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[a][1], 0, 0, 0);
-            }
-        }
     }
+    if (nfull > 0 && tail) {
+        fetch_tail(nfull * KT);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(buf);
+        __builtin_amdgcn_sched_barrier(0);
+        stash(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    multiply(buf);
 
-    // epilogue: D tile layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // epilogue: D tile layout col = lane&15, row = 4*(lane>>4) + reg
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int64_t n = n0 + wn * 64 + b * 32 + l31;
+    for (int b = 0; b < TN; ++b) {
+        const int64_t n = n0 + wn * 16 * TN + b * 16 + i16;
         if (n >= N) continue;
         const float bv = bias ? bias[n] : 0.0f;
 #pragma unroll
-        for (int a = 0; a < MT; ++a) {
+        for (int a = 0; a < TM; ++a) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t m = m0 + wm * 32 * MT + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            for (int r = 0; r < 4; ++r) {
+                const int64_t m = m0 + wm * 16 * TM + a * 16 + 4 * kg + r;
                 if (m < M) {
                     float v = acc[a][b][r];
                     if (bias) v = v + bv;
@@ -196,33 +182,37 @@ k_linear(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t l
 
 using namespace gm;
 
-template <int MT>
+template <int TM, int TN, int KT, int OCC, int WGM = 2, int WGN = 2>
 static int launch_linear(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw,
-                         const float* bias, float* C, int64_t ldc, int relu, hipStream_t s) {
-    constexpr int BM = 64 * MT;
-#ifdef GM_GEMM_XCD
-    const int64_t total_tiles = ((N + BN - 1) / BN) * ((M + BM - 1) / BM);
-    dim3 grid((unsigned)(((total_tiles + 7) / 8) * 8)), block(256);
-#else
-    dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + BM - 1) / BM)), block(256);
-    GM_REQUIRE(grid.y < 65536u * 16u, "M too large");
-#endif
+                           const float* bias, float* C, int64_t ldc, int relu, hipStream_t s) {
+    constexpr int SBM = 16 * TM * WGM, SBN = 16 * TN * WGN;
+    const int64_t total_tiles = ((N + SBN - 1) / SBN) * ((M + SBM - 1) / SBM);
+    GM_REQUIRE(total_tiles < (1ll << 31) - 8, "too many tiles");
+    dim3 grid((unsigned)(((total_tiles + 7) / 8) * 8)), block(64 * WGM * WGN);
     const bool v4 = lda % 4 == 0 && ldw % 4 == 0 && aligned(A, 16) && aligned(W, 16);
     const bool v2 = lda % 2 == 0 && ldw % 2 == 0 && aligned(A, 8) && aligned(W, 8);
-    if (v4) hipLaunchKernelGGL((k_linear<4, MT>), grid, block, 0, s, M, N, K, A, lda, W, ldw, bias, C, ldc, relu);
-    else if (v2) hipLaunchKernelGGL((k_linear<2, MT>), grid, block, 0, s, M, N, K, A, lda, W, ldw, bias, C, ldc, relu);
-    else hipLaunchKernelGGL((k_linear<1, MT>), grid, block, 0, s, M, N, K, A, lda, W, ldw, bias, C, ldc, relu);
+    if (v4) hipLaunchKernelGGL((k_linear<4, TM, TN, KT, OCC, WGM, WGN>), grid, block, 0, s, M, N, K, A, lda, W, ldw, bias, C, ldc, relu);
+    else if (v2) hipLaunchKernelGGL((k_linear<2, TM, TN, KT, OCC, WGM, WGN>), grid, block, 0, s, M, N, K, A, lda, W, ldw, bias, C, ldc, relu);
+    else hipLaunchKernelGGL((k_linear<1, TM, TN, KT, OCC, WGM, WGN>), grid, block, 0, s, M, N, K, A, lda, W, ldw, bias, C, ldc, relu);
     GM_LAUNCH_CHECK();
     return GM_OK;
 }
+
+#ifndef GM_GEMM_BIG_TILES
+#define GM_GEMM_BIG_TILES 400   // at least this many 128x128 tiles: the 128x128 / 8-wave configuration
+#endif
 
 extern "C" int gm_linear(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw,
                          const float* bias, float* C, int64_t ldc, int relu, gm_stream_t stream) {
     GM_REQUIRE(M > 0 && N > 0 && K > 0 && A && W && C, "bad arguments");
     GM_REQUIRE(lda >= K && ldw >= K && ldc >= N, "leading dimension too small");
     hipStream_t s = as_stream(stream);
-    // fewer than ~3 workgroups per CU at the 128-row tiling: halve the tile height (same arithmetic per output)
-    const int64_t tiles128 = ((N + BN - 1) / BN) * ((M + 127) / 128);
-    if (tiles128 < GM_GEMM_SMALL_TILES) return launch_linear<1>(M, N, K, A, lda, W, ldw, bias, C, ldc, relu, s);
-    return launch_linear<2>(M, N, K, A, lda, W, ldw, bias, C, ldc, relu, s);
+#ifdef GM_GEMM_CFG   // exploration builds (tools/build_gemm_variant.sh): one configuration for every shape
+    return launch_linear<GM_GEMM_CFG>(M, N, K, A, lda, W, ldw, bias, C, ldc, relu, s);
+#endif
+    const int64_t tiles128 = ((N + 127) / 128) * ((M + 127) / 128);
+    // wide layers with many rows: 128x128 block tile, 4x2 waves of 32x64 (half the operand traffic per FLOP);
+    // everything else: 64x64 block tile, 2x2 waves of 32x32, four workgroups per CU
+    if (tiles128 >= GM_GEMM_BIG_TILES) return launch_linear<2, 4, 32, 2, 4, 2>(M, N, K, A, lda, W, ldw, bias, C, ldc, relu, s);
+    return launch_linear<2, 2, 32, 4>(M, N, K, A, lda, W, ldw, bias, C, ldc, relu, s);
 }
