@@ -45,7 +45,12 @@ struct PairArgs {
     const uint32_t* bits_t;
     int64_t wpr;
     float tab[8];
-    int64_t row_begin, row_end;
+    // up to MAXR row ranges of the pair matrix in one launch (a rank's folded chunks): range r covers rows
+    // [row_begin[r], row_end[r]) and owns tiles [tile_base[r], tile_base[r+1]) of the shared tile counter
+    int nranges;
+    int64_t row_begin[4], row_end[4];
+    int nti[4], tjb[4];
+    int64_t tile_base[5];
     const float* u;
     uint64_t seed;
     uint32_t step;
@@ -53,11 +58,31 @@ struct PairArgs {
     float* logits_dbg;
     float* post_dbg;
     uint32_t* counter;
-    int nti, ntj, tjb;
+    int ntj;
     int64_t ntiles;
 };
+constexpr int MAXR = 4;
 
 __host__ __device__ __forceinline__ int64_t tile_prefix(int64_t ti, int64_t width) { return ti * width - ti * (ti - 1) / 2; }
+
+// tile index t of the launch -> first row i0 / first column j0 / column-tile tj / end row of the range it belongs to
+__device__ __forceinline__ void decode_tile(const PairArgs& a, int64_t t, int64_t& i0, int64_t& j0, int& tj, int64_t& row_end) {
+    int r = 0;
+#pragma unroll
+    for (int q = 1; q < MAXR; ++q)
+        if (q < a.nranges && t >= a.tile_base[q]) r = q;
+    const int64_t tl = t - a.tile_base[r];
+    const int64_t width = (int64_t)a.ntj - a.tjb[r];
+    int lo = 0, hi = a.nti[r] - 1;          // largest ti with prefix(ti) <= tl
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tile_prefix(mid, width) <= tl) lo = mid; else hi = mid - 1;
+    }
+    tj = a.tjb[r] + lo + (int)(tl - tile_prefix(lo, width));
+    i0 = a.row_begin[r] + (int64_t)lo * TILE;
+    j0 = (int64_t)tj * TILE;
+    row_end = a.row_end[r];
+}
 
 // store a float4 of 4 consecutive k into the [even k | odd k] row image
 __device__ __forceinline__ void put_split(float* row, int c4, float4 v) {
@@ -157,7 +182,6 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
     if (tid < HE) b1s[tid] = a.b1[tid];
     if (tid < 2 * HE) W2s[tid] = a.W2[tid];
     const float b20 = a.b2[0], b21 = a.b2[1];
-    const int64_t width = (int64_t)a.ntj - a.tjb;
 
     if (tid == 0) *tile_s = (int)atomicAdd(a.counter, 1u);
     if (tid < 8) turn_s[tid] = 0;
@@ -173,16 +197,9 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
 #endif
 
     while (t < a.ntiles) {
-        // decode t -> (ti, tj): largest ti with prefix(ti) <= t
-        int lo = 0, hi = a.nti - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (tile_prefix(mid, width) <= t) lo = mid; else hi = mid - 1;
-        }
-        const int ti = lo;
-        const int tj = a.tjb + ti + (int)(t - tile_prefix(ti, width));
-        const int64_t i0 = a.row_begin + (int64_t)ti * TILE;
-        const int64_t j0 = (int64_t)tj * TILE;
+        int64_t i0, j0, row_end;
+        int tj;
+        decode_tile(a, t, i0, j0, tj, row_end);
 
         if (!staged) {   // first tile of this workgroup; later tiles are staged at the hand-over below
             stage_tile(a.h, a.n, i0, j0, hIs, hJs, tid);
@@ -206,7 +223,7 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
             }
             __builtin_amdgcn_sched_barrier(0);
             {
-                if (i < a.row_end && i < a.n) {                  // wave-uniform
+                if (i < row_end && i < a.n) {                    // wave-uniform
 #ifdef GM_PAIR_STAMP
                     const unsigned long long m0 = STAMP();
 #endif
@@ -270,7 +287,7 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
                     for (int mt = 0; mt < 4; ++mt) asm volatile("" ::"v"(acc[s][mt]));
                 if (false) {
 #else
-                if (i < a.row_end && i < a.n) {
+                if (i < row_end && i < a.n) {
 #endif
                     // ---- second layer: in-lane dot over this lane's 64 hidden units, both strips
                     float part[2][2];
@@ -348,13 +365,9 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
         __syncthreads();
         t = *tile_s;
         if (t < a.ntiles) {
-            int lo2 = 0, hi2 = a.nti - 1;
-            while (lo2 < hi2) {
-                const int mid = (lo2 + hi2 + 1) >> 1;
-                if (tile_prefix(mid, width) <= t) lo2 = mid; else hi2 = mid - 1;
-            }
-            const int64_t ni0 = a.row_begin + (int64_t)lo2 * TILE;
-            const int64_t nj0 = (int64_t)(a.tjb + lo2 + (int)(t - tile_prefix(lo2, width))) * TILE;
+            int64_t ni0, nj0, nre;
+            int ntj_;
+            decode_tile(a, t, ni0, nj0, ntj_, nre);
             stage_tile(a.h, a.n, ni0, nj0, hIs, hJs, tid);
         }
         staged = true;
@@ -372,31 +385,45 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
 
 using namespace gm;
 
-extern "C" int gm_pair_score_sample(int64_t n, int64_t hE, const float* h, const float* W1, const float* b1, const float* W2,
-                                    const float* b2, const uint32_t* bits_t, int64_t wpr, const float* tab, int64_t row_begin,
-                                    int64_t row_end, const float* u, uint64_t seed, uint32_t step, uint32_t* out_upper,
-                                    float* logits_dbg, float* post_dbg, void* workspace, gm_stream_t stream) {
+extern "C" int gm_pair_score_sample_ranges(int64_t n, int64_t hE, const float* h, const float* W1, const float* b1,
+                                           const float* W2, const float* b2, const uint32_t* bits_t, int64_t wpr,
+                                           const float* tab, int nranges, const int64_t* row_ranges, const float* u,
+                                           uint64_t seed, uint32_t step, uint32_t* out_upper, float* logits_dbg,
+                                           float* post_dbg, void* workspace, gm_stream_t stream) {
     GM_REQUIRE(hE == HE, "hidden_E=%lld is not supported: the pair kernel is built for hidden_E=128", (long long)hE);
     GM_REQUIRE(n > 1 && n < (1ll << 31), "n out of range");
     GM_REQUIRE(wpr >= (n + 31) / 32 && wpr % 4 == 0, "bad wpr");
     GM_REQUIRE(h && W1 && b1 && W2 && b2 && bits_t && tab && out_upper && workspace, "null pointer");
     GM_REQUIRE(aligned(h, 16) && aligned(W1, 16), "h and W1 must be 16-byte aligned");
-    GM_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= n, "bad row range [%lld,%lld)", (long long)row_begin,
-               (long long)row_end);
-    if (row_begin == row_end) return GM_OK;
+    GM_REQUIRE(nranges >= 1 && nranges <= MAXR && row_ranges, "between 1 and %d row ranges", MAXR);
     hipStream_t s = as_stream(stream);
     PairArgs a;
     a.n = n; a.h = h; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.bits_t = bits_t; a.wpr = wpr;
     for (int k = 0; k < 8; ++k) a.tab[k] = tab[k];
-    a.row_begin = row_begin; a.row_end = row_end; a.u = u; a.seed = seed; a.step = step;
+    a.u = u; a.seed = seed; a.step = step;
     a.out_upper = out_upper; a.logits_dbg = logits_dbg; a.post_dbg = post_dbg;
     a.counter = static_cast<uint32_t*>(workspace);
-    // rows beyond the last one that has a partner (i = n-1) still get their (all-zero) words written
-    a.nti = (int)((row_end - row_begin + TILE - 1) / TILE);
     a.ntj = (int)((n + TILE - 1) / TILE);
-    a.tjb = (int)(row_begin / TILE);
-    const int64_t width = (int64_t)a.ntj - a.tjb;
-    a.ntiles = tile_prefix(a.nti, width);
+    a.nranges = 0;
+    a.tile_base[0] = 0;
+    for (int r = 0; r < MAXR; ++r) { a.row_begin[r] = a.row_end[r] = 0; a.nti[r] = 0; a.tjb[r] = 0; a.tile_base[r + 1] = 0; }
+    int64_t prev_end = 0;
+    for (int r = 0; r < nranges; ++r) {
+        const int64_t rb = row_ranges[2 * r], re = row_ranges[2 * r + 1];
+        GM_REQUIRE(0 <= rb && rb <= re && re <= n, "bad row range [%lld,%lld)", (long long)rb, (long long)re);
+        GM_REQUIRE(rb >= prev_end, "row ranges must be ascending and disjoint");   // two tiles never write one row word
+        prev_end = re;
+        if (rb == re) continue;
+        const int q = a.nranges++;
+        a.row_begin[q] = rb; a.row_end[q] = re;
+        // rows beyond the last one that has a partner (i = n-1) still get their (all-zero) words written
+        a.nti[q] = (int)((re - rb + TILE - 1) / TILE);
+        a.tjb[q] = (int)(rb / TILE);
+        a.tile_base[q + 1] = a.tile_base[q] + tile_prefix(a.nti[q], (int64_t)a.ntj - a.tjb[q]);
+    }
+    if (a.nranges == 0) return GM_OK;
+    for (int q = a.nranges; q < MAXR; ++q) a.tile_base[q + 1] = a.tile_base[a.nranges];
+    a.ntiles = a.tile_base[a.nranges];
     GM_REQUIRE(a.ntiles > 0 && a.ntiles < (1ll << 31), "tile count out of range");
     int dev = 0, cus = 0;
     GM_HIP(hipGetDevice(&dev));
@@ -407,4 +434,13 @@ extern "C" int gm_pair_score_sample(int64_t n, int64_t hE, const float* h, const
     hipLaunchKernelGGL(k_pair_score_sample, dim3(grid), dim3(PAIR_THREADS), 0, s, a);
     GM_LAUNCH_CHECK();
     return GM_OK;
+}
+
+extern "C" int gm_pair_score_sample(int64_t n, int64_t hE, const float* h, const float* W1, const float* b1, const float* W2,
+                                    const float* b2, const uint32_t* bits_t, int64_t wpr, const float* tab, int64_t row_begin,
+                                    int64_t row_end, const float* u, uint64_t seed, uint32_t step, uint32_t* out_upper,
+                                    float* logits_dbg, float* post_dbg, void* workspace, gm_stream_t stream) {
+    const int64_t range[2] = {row_begin, row_end};
+    return gm_pair_score_sample_ranges(n, hE, h, W1, b1, W2, b2, bits_t, wpr, tab, 1, range, u, seed, step, out_upper,
+                                       logits_dbg, post_dbg, workspace, stream);
 }

@@ -257,11 +257,9 @@ class BaseModel(nn.Module):
         W1, b1, W2, b2 = pred_E.pair_params()
         ranges = [(0, n)] if plan is None else plan.pair_chunks()
         upper = torch.zeros((n, bits_t.shape[1]), dtype=torch.int32, device=h.device)
-        with self.phase("pair"):
-            for r0, r1 in ranges:
-                if r1 > r0:
-                    ops.pair_score_sample(h, W1, b1, W2, b2, bits_t, tab_E, seed=seed, step=step, u=u, row_begin=r0,
-                                          row_end=r1, out_upper=upper, workspace=self._pair_ws)
+        with self.phase("pair"):      # a rank's two folded chunks go into ONE launch (shared tile queue)
+            ops.pair_score_sample(h, W1, b1, W2, b2, bits_t, tab_E, seed=seed, step=step, u=u, row_ranges=ranges,
+                                  out_upper=upper, workspace=self._pair_ws)
         if plan is not None:
             with self.phase("allgather_E"):
                 parallel.gather_upper_rows(plan, upper, group)

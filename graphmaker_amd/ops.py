@@ -158,9 +158,9 @@ def hadamard_gather(h, src, dst):
 
 # ------------------------------------------------------------------ structure denoiser
 def pair_score_sample(h, W1, b1, W2, b2, bits_t, tab, *, seed=0, step=0, u=None, row_begin=0, row_end=None,
-                      out_upper=None, workspace=None, want_debug=False):
-    """All pairs i<j of rows [row_begin,row_end): returns the upper-triangle bitmap of E_s
-    (and (P,2) logits / posteriors when want_debug)."""
+                      row_ranges=None, out_upper=None, workspace=None, want_debug=False):
+    """All pairs i<j of rows [row_begin,row_end) -- or of up to four ascending, disjoint `row_ranges` [(b0,e0),...] in
+    one launch: returns the upper-triangle bitmap of E_s (and (P,2) logits / posteriors when want_debug)."""
     require(h, torch.float32, "h")
     require(bits_t, torch.int32, "bits_t")
     n, hE = h.shape
@@ -179,9 +179,13 @@ def pair_score_sample(h, W1, b1, W2, b2, bits_t, tab, *, seed=0, step=0, u=None,
         require(u, torch.float32, "u")
         if u.numel() != P:
             raise ValueError(f"u has {u.numel()} entries, expected P={P}")
-    L.call("gm_pair_score_sample", I64(n), I64(hE), ptr(h), ptr(W1), ptr(b1), ptr(W2), ptr(b2), ptr(bits_t), I64(wpr),
-           tab_host, I64(row_begin), I64(row_end), ptr(u), U64(seed), U32(step), ptr(out_upper), ptr(lg), ptr(po),
-           ptr(workspace), stream_ptr())
+    if row_ranges is None:
+        row_ranges = [(row_begin, row_end)]
+    flat = [int(v) for be in row_ranges for v in be]
+    ranges_host = (C.c_int64 * len(flat))(*flat)
+    L.call("gm_pair_score_sample_ranges", I64(n), I64(hE), ptr(h), ptr(W1), ptr(b1), ptr(W2), ptr(b2), ptr(bits_t),
+           I64(wpr), tab_host, I32(len(flat) // 2), ranges_host, ptr(u), U64(seed), U32(step), ptr(out_upper), ptr(lg),
+           ptr(po), ptr(workspace), stream_ptr())
     return (out_upper, lg, po) if want_debug else out_upper
 
 

@@ -128,6 +128,14 @@ int gm_pair_score_sample(int64_t n, int64_t hE, const float* h, const float* W1,
                          int64_t row_begin, int64_t row_end, const float* u, uint64_t seed, uint32_t step,
                          uint32_t* out_upper, float* logits_dbg, float* post_dbg, void* workspace,
                          gm_stream_t stream);
+/* The same loop over up to 4 ascending, disjoint row ranges in ONE launch (row_ranges: HOST array
+ * [begin0,end0,begin1,end1,...]): the per-GPU share of the pair matrix is two folded row chunks, and one launch with a
+ * shared tile queue keeps every CU busy where two back-to-back launches each end with a partly idle chip. */
+int gm_pair_score_sample_ranges(int64_t n, int64_t hE, const float* h, const float* W1, const float* b1,
+                                const float* W2, const float* b2, const uint32_t* bits_t, int64_t wpr, const float* tab,
+                                int nranges, const int64_t* row_ranges, const float* u, uint64_t seed, uint32_t step,
+                                uint32_t* out_upper, float* logits_dbg, float* post_dbg, void* workspace,
+                                gm_stream_t stream);
 
 /* ---- attribute posterior + draw: model/diffusion.py:879-895 + sample_X :214-237 ----
  * logits (n,F,2); tab device (F,8) per-attribute posterior tables; x_s (n,F) uint8; onehot_out optional (n,2F).

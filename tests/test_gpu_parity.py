@@ -327,6 +327,19 @@ def test_pair_kernel_large_against_oracle_rows_and_sharding(dev):
     for r0, r1 in [(0, 700), (700, 1801), (1801, n)]:
         ops.pair_score_sample(*args, bits_t(bits, dev), tab, seed=99, step=2, row_begin=r0, row_end=r1, out_upper=out)
     assert torch.equal(ops.symmetrize_upper(out, n), sym)
+    # the same ranges (unaligned starts, an empty one) in ONE launch with a shared tile queue; and a rank's folded chunks
+    out1 = torch.zeros_like(full)
+    ops.pair_score_sample(*args, bits_t(bits, dev), tab, seed=99, step=2, out_upper=out1,
+                          row_ranges=[(0, 700), (700, 700), (700, 1801), (1801, n)])
+    assert torch.equal(out1, out)
+    from graphmaker_amd.parallel import ShardPlan
+    out2 = torch.zeros_like(full)
+    for r in range(3):
+        ops.pair_score_sample(*args, bits_t(bits, dev), tab, seed=99, step=2, out_upper=out2,
+                              row_ranges=ShardPlan.make(n, 3, r).pair_chunks())
+    assert torch.equal(ops.symmetrize_upper(out2, n), sym)
+    with pytest.raises(Exception):      # overlapping / descending ranges are refused
+        ops.pair_score_sample(*args, bits_t(bits, dev), tab, seed=99, step=2, row_ranges=[(640, 1280), (0, 640)])
     # oracle on three row bands (first, middle across tile borders, last)
     pair = orc.PairMLP(W1, b1, W2, b2)
     got = bits_np(full)
@@ -395,9 +408,7 @@ def test_rank_shards_reproduce_single_gpu_step(dev, world):
     assert torch.equal(h, h_full) and torch.equal(lg, lg_full)
     for r in range(world):
         plan = ShardPlan.make(N, world, r)
-        for r0, r1 in plan.pair_chunks():
-            if r1 > r0:
-                ops.pair_score_sample(h, W1, b1, W2, b2, bits, tab_E, seed=seed, step=T, row_begin=r0, row_end=r1, out_upper=up)
+        ops.pair_score_sample(h, W1, b1, W2, b2, bits, tab_E, seed=seed, step=T, row_ranges=plan.pair_chunks(), out_upper=up)
         ops.attr_posterior_sample(lg, x_in, t_(tab_X, dev), seed=seed, step=T, rows=plan.node_range(), x_s=xs,
                                   want_onehot=False)
     assert torch.equal(ops.symmetrize_upper(up, N), ops.symmetrize_upper(up_full, N))
