@@ -256,7 +256,8 @@ class BaseModel(nn.Module):
             self._pair_ws = torch.empty(256, dtype=torch.uint8, device=h.device)
         W1, b1, W2, b2 = pred_E.pair_params()
         ranges = [(0, n)] if plan is None else plan.pair_chunks()
-        upper = torch.zeros((n, bits_t.shape[1]), dtype=torch.int32, device=h.device)
+        upper = torch.zeros((n if plan is None else plan.padded_pair_rows, bits_t.shape[1]), dtype=torch.int32,
+                            device=h.device)
         with self.phase("pair"):      # a rank's two folded chunks go into ONE launch (shared tile queue)
             ops.pair_score_sample(h, W1, b1, W2, b2, bits_t, tab_E, seed=seed, step=step, u=u, row_ranges=ranges,
                                   out_upper=upper, workspace=self._pair_ws)
@@ -264,7 +265,7 @@ class BaseModel(nn.Module):
             with self.phase("allgather_E"):
                 parallel.gather_upper_rows(plan, upper, group)
         with self.phase("symmetrize"):
-            bits_s = ops.symmetrize_upper(upper, n)
+            bits_s = ops.symmetrize_upper(upper[:n], n)
         return A_t, bits_s
 
     def _logits_fn(self, pred_X, t_float, x_onehot, Y32, A_t, plan, group):
@@ -386,11 +387,64 @@ class ModelSync(BaseModel):
         t_float = torch.tensor([t / self.T], dtype=torch.float32).to(dev)      # :860
         uE = uniforms.get(("E", t)) if uniforms else None
         uX = uniforms.get(("X", t)) if uniforms else None
+        if plan is not None:
+            return self._denoise_step_sharded(t, t_float, x, x_onehot, Y32, bits_t, tab_E, tab_X, seed, uE, uX, plan, group)
         A_t, bits_s = self._structure_step(self.graph_encoder.pred_E, t_float, x_onehot, Y32, bits_t, tab_E, seed, t,
                                            u=uE, plan=plan, group=group)
         pred_X = self.graph_encoder.pred_X                                      # A_t of E_t, not E_s (:875-878)
         x_s, oh_s = self._attribute_draw(self._logits_fn(pred_X, t_float, x_onehot, Y32, A_t, plan, group), x, tab_X,
                                          seed, t, u=uX, plan=plan, group=group)
+        return x_s, oh_s, bits_s
+
+    def _denoise_step_sharded(self, t, t_float, x, x_onehot, Y32, bits_t, tab_E, tab_X, seed, uE, uX, plan, group):
+        """denoise_step on one rank of the one-process-per-GPU decomposition (parallel.py), scheduled so that the
+        transfers hide under compute.  Both towers read the same A_t / X_t / Y (the attribute tower uses A_t of E_t,
+        model/diffusion.py:875-878), so their row-sharded stages are issued alternately: while the [h_X | h_Y] rows of
+        one tower's stage are on the wire, the other tower's stage computes.  The attribute draw runs before the pair
+        kernel and its all-gather travels under it.  Every rank issues the collectives in the same order.  Draws are
+        keyed on global indices, so the result is bit-identical to the single-GPU step."""
+        n, dev = self.num_nodes, x.device
+        ge = self.graph_encoder
+        enc, pred_X = ge.pred_E.gnn_encoder, ge.pred_X
+        with self.phase("csr"):
+            A_t = ops.adjacency_from_bitmap(bits_t, n)
+        h_pad = self._buf("h_pad", (plan.world * plan.node_rows, enc._dims.out_size), torch.float32, dev)
+        logits = self._buf("logits", (n, pred_X._dims.out_size), torch.float32, dev)
+        x_pad = self._buf("x_pad", (plan.world * plan.node_rows, x.shape[1]), torch.uint8, dev)
+        start = parallel.start_all_gather_node_rows
+        with self.phase("towers"):
+            stages = [enc._sharded_stages(t_float, x_onehot, Y32, A_t, plan, group, h_pad[:n], start),
+                      pred_X._sharded_stages(t_float, x_onehot, Y32, A_t, plan, group, logits, start)]
+            while stages:
+                for g in list(stages):
+                    try:
+                        next(g)
+                    except StopIteration:
+                        stages.remove(g)
+        h_on_wire = start(plan, h_pad, group)                        # node embeddings of every rank (pair kernel input)
+        with self.phase("attr"):                                     # ... while this rank draws its attribute rows
+            ops.attr_posterior_sample(logits, x, torch.from_numpy(tab_X).to(dev), seed=seed, step=t, u=uX,
+                                      rows=plan.node_range(), x_s=x_pad[:n], want_onehot=False)
+        x_on_wire = start(plan, x_pad, group)                        # travels under the pair kernel
+        with self.phase("allgather_h"):
+            h_on_wire.wait()
+        h = h_pad[:n]
+        if self._pair_ws is None or self._pair_ws.device != dev:
+            self._pair_ws = torch.empty(256, dtype=torch.uint8, device=dev)
+        W1, b1, W2, b2 = ge.pred_E.pair_params()
+        upper = torch.zeros((plan.padded_pair_rows, bits_t.shape[1]), dtype=torch.int32, device=dev)
+        with self.phase("pair"):
+            ops.pair_score_sample(h, W1, b1, W2, b2, bits_t, tab_E, seed=seed, step=t, u=uE,
+                                  row_ranges=plan.pair_chunks(), out_upper=upper, workspace=self._pair_ws)
+        with self.phase("allgather_E"):
+            parallel.gather_upper_rows(plan, upper, group)
+        with self.phase("symmetrize"):
+            bits_s = ops.symmetrize_upper(upper[:n], n)
+        with self.phase("allgather_X"):
+            x_on_wire.wait()
+            x_s = x_pad[:n].clone()                                  # x_pad is reused by the next step
+        with self.phase("attr"):
+            oh_s = ops.onehot_from_x(x_s)
         return x_s, oh_s, bits_s
 
     @torch.no_grad()

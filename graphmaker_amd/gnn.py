@@ -137,6 +137,20 @@ class _TowerBase(nn.Module):
         """Row-sharded forward for the one-process-per-GPU decomposition: this rank computes node rows
         plan.node_range() of every stage; before each message-passing layer the [h_X | h_Y] rows of all ranks are
         replicated by `gather` (parallel.all_gather_node_rows).  Writes rows node_range() of `out` (n, out_size)."""
+        class _Now:
+            def __init__(self, *a):
+                gather(*a)
+
+            def wait(self):
+                pass
+        for _ in self._sharded_stages(t_float, X_t_one_hot, Y_real, A_t, plan, group, out, _Now):
+            pass
+        return out
+
+    def _sharded_stages(self, t_float, X_t_one_hot, Y_real, A_t, plan, group, out, gather_start):
+        """_run_sharded as a generator: it yields right after each all-gather has been STARTED
+        (gather_start(plan, buffer, group) -> handle with .wait(), parallel.start_all_gather_node_rows) and waits for it
+        when resumed, so the caller can enqueue other kernels (the other tower's stage) under the transfer."""
         n = X_t_one_hot.shape[0]
         X = X_t_one_hot if X_t_one_hot.is_contiguous() else X_t_one_hot.contiguous()
         Y32 = (Y_real if Y_real.dtype == torch.int32 else Y_real.to(torch.int32)).contiguous()
@@ -154,11 +168,15 @@ class _TowerBase(nn.Module):
             bufs = self._gather_bufs
         ops.tower_stage(d, ptrs, n, -1, rows, ws, t_float=t, X_one_hot=X, Y32=Y32, layer_dst=bufs[0])
         for l in range(d.num_layers):
-            src = gather(plan, bufs[l & 1], group) if need_gather else None
+            src = None
+            if need_gather:
+                handle = gather_start(plan, bufs[l & 1], group)
+                yield
+                handle.wait()
+                src = bufs[l & 1]
             dst = bufs[(l + 1) & 1] if need_gather and l + 1 < d.num_layers else None
             ops.tower_stage(d, ptrs, n, l, rows, ws, adj=A_t, layer_src=src, layer_dst=dst)
         ops.tower_stage(d, ptrs, n, d.num_layers, rows, ws, out=out)
-        return out
 
 
 class GNNTower(_TowerBase):

@@ -49,6 +49,12 @@ class ShardPlan:
         r = self.rank if rank is None else rank
         return min(r * self.node_rows, self.n), min((r + 1) * self.node_rows, self.n)
 
+    @property
+    def padded_pair_rows(self):
+        """2G chunks of chunk_rows rows: the row count of an upper-triangle bitmap that gather_upper_rows can pack and
+        unpack chunk-wise (>= n; the rows past n are never read)."""
+        return 2 * self.world * self.chunk_rows
+
     def pairs_of(self, rank):
         n = self.n
         tot = 0
@@ -57,13 +63,46 @@ class ShardPlan:
         return tot
 
 
+class _Done:
+    def wait(self):
+        pass
+
+
+def _is_rccl(group):
+    return dist.get_backend(group) == "nccl"
+
+
+def _all_gather(out, inp, group, async_op=False):
+    """One equal-sized all-gather.  RCCL (the product transport): stream-ordered, may be left in flight (async_op).
+    Any other backend (gloo: the CPU tests, and GPU tests whose ranks share one device) is completed here, and device
+    tensors are staged through host copies made HERE: gloo's own handling of device tensors hung on this stack (ROCm 7,
+    several ranks on one GPU), with one collective in flight as well as with two."""
+    if _is_rccl(group):
+        work = dist.all_gather_into_tensor(out, inp, group=group, async_op=async_op)
+        return work if async_op else _Done()
+    if out.is_cuda:
+        host_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host_out, inp.cpu(), group=group)
+        out.copy_(host_out)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+    return _Done()
+
+
 def all_gather_node_rows(plan, full, group=None):
     """`full` is an (n_pad, cols) tensor with n_pad = world*node_rows whose rows node_range(rank) are valid on this
     rank; after the call every rank holds all rows.  One equal-sized all-gather, in place."""
     r0 = plan.rank * plan.node_rows
-    local = full[r0:r0 + plan.node_rows]
-    dist.all_gather_into_tensor(full, local.contiguous(), group=group)
+    _all_gather(full, full[r0:r0 + plan.node_rows], group)
     return full
+
+
+def start_all_gather_node_rows(plan, full, group=None):
+    """all_gather_node_rows, started but not waited for: returns the Work handle.  The collective runs on the backend's
+    own stream after everything already enqueued on the current stream; `handle.wait()` makes the current stream wait
+    for it (no host block under RCCL), so kernels enqueued in between overlap with the transfer."""
+    r0 = plan.rank * plan.node_rows
+    return _all_gather(full, full[r0:r0 + plan.node_rows], group, async_op=True)
 
 
 _scratch = {}
@@ -79,21 +118,33 @@ def _persistent(name, shape, dtype, device):
 
 
 def gather_upper_rows(plan, upper, group=None):
-    """`upper` is the (n, wpr) int32 upper-triangle bitmap whose rows pair_chunks(rank) were written on this rank.
-    After the call every rank holds every row.  Pack (2a rows) -> one all-gather -> unpack."""
+    """`upper` is the (>= n, wpr) int32 upper-triangle bitmap whose rows pair_chunks(rank) were written on this rank; give
+    it plan.padded_pair_rows rows and the pack / unpack are one kernel each.  After the call every rank holds every row.
+    Pack (this rank's two chunks, 2a rows) -> one equal-sized all-gather -> unpack (slot 2r+k -> chunk r or 2G-1-r)."""
     a, w = plan.chunk_rows, plan.world
     wpr = upper.shape[1]
-    send = _persistent("send", (2 * a, wpr), upper.dtype, upper.device)   # rows beyond a short chunk stay zero
+    send = _persistent("send", (2, a, wpr), upper.dtype, upper.device)      # rows beyond a short chunk stay zero
+    recv = _persistent("recv", (2 * w, a, wpr), upper.dtype, upper.device)
+    if upper.shape[0] >= 2 * w * a:
+        chunks = upper[:2 * w * a].view(2 * w, a, wpr)
+        key = ("slots", w, plan.rank, upper.device)
+        if key not in _scratch:
+            slot_chunk = [r if k == 0 else 2 * w - 1 - r for r in range(w) for k in range(2)]
+            _scratch[key] = (torch.tensor(slot_chunk[2 * plan.rank:2 * plan.rank + 2], device=upper.device),
+                             torch.tensor(slot_chunk, device=upper.device))
+        mine, slot_chunk = _scratch[key]
+        torch.index_select(chunks, 0, mine, out=send)
+        _all_gather(recv.view(2 * w * a, wpr), send.view(2 * a, wpr), group)
+        chunks.index_copy_(0, slot_chunk, recv)
+        return upper
     for k, (b, e) in enumerate(plan.pair_chunks()):
         if e > b:
-            send[k * a:k * a + (e - b)] = upper[b:e]
-    recv = _persistent("recv", (w * 2 * a, wpr), upper.dtype, upper.device)
-    dist.all_gather_into_tensor(recv, send, group=group)
-    recv = recv.view(w, 2 * a, wpr)
+            send[k, :e - b] = upper[b:e]
+    _all_gather(recv.view(2 * w * a, wpr), send.view(2 * a, wpr), group)
     for r in range(w):
         if r == plan.rank:
             continue
         for k, (b, e) in enumerate(plan.pair_chunks(r)):
             if e > b:
-                upper[b:e] = recv[r, k * a:k * a + (e - b)]
+                upper[b:e] = recv[2 * r + k, :e - b]
     return upper

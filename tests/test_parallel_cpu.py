@@ -48,16 +48,23 @@ def _worker(rank, world, port, name, q):
         h_pad = torch.zeros((world * plan.node_rows, h_full.shape[1]), dtype=torch.float32)
         b, e = plan.node_range()
         h_pad[b:e] = torch.from_numpy(h_full[b:e])
-        h = all_gather_node_rows(plan, h_pad)[:N].numpy()
+        if rank == 0:                                       # the started-then-waited form used by the overlapped schedule
+            from graphmaker_amd.parallel import start_all_gather_node_rows
+            start_all_gather_node_rows(plan, h_pad).wait()
+            h = h_pad[:N].numpy()
+        else:
+            h = all_gather_node_rows(plan, h_pad)[:N].numpy()
         ok_h = np.array_equal(h, h_full)
 
         # 2) pair matrix: this rank scores its two folded row chunks, then the rows are gathered
-        upper = torch.zeros((N, bits.shape[1]), dtype=torch.int32)
+        # (padded to whole chunks: pack / unpack are one kernel each; world 3 also takes the row-range fallback)
+        upper = torch.zeros((plan.padded_pair_rows if world == 2 else N, bits.shape[1]), dtype=torch.int32)
         for r0, r1 in plan.pair_chunks():
             if r1 > r0:
                 part = orc.pair_score_sample(N, h, pair, bits, tab, seed=seed, step=t, row_begin=r0, row_end=r1)
                 upper[r0:r1] = torch.from_numpy(part[r0:r1].view(np.int32))
         gather_upper_rows(plan, upper)
+        upper = upper[:N].contiguous()
         sym = orc.symmetrize_upper(upper.numpy().view(np.uint32), N)
         want = orc.symmetrize_upper(orc.pair_score_sample(N, h_full, pair, bits, tab, seed=seed, step=t), N)
         ok_e = np.array_equal(sym, want)
