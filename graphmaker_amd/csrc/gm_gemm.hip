@@ -83,24 +83,35 @@ k_linear(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t l
         const int64_t r = n0 + srow + RSTEP * c;
         pw[c] = W + (r < N ? r : N - 1) * ldw + skq;
     }
-    float4 ra[NA], rb[NB];
-    auto fetch_fast = [&](int64_t k0) {
-#pragma unroll
-        for (int c = 0; c < NA; ++c) ra[c] = load_k4<VEC, false>(pa[c] + k0, 0, 0);
-#pragma unroll
-        for (int c = 0; c < NB; ++c) rb[c] = load_k4<VEC, false>(pw[c] + k0, 0, 0);
+    // Two register sets: while tile t is multiplied, tile t+1 sits in one set (loads issued an iteration ago) and tile
+    // t+2 is being loaded into the other.  A load therefore has a whole iteration plus a multiply phase to land before
+    // its s_waitcnt, and a slow load no longer holds the whole workgroup at the barrier (with one set the barrier made
+    // every wave wait for the slowest wave's loads: 13% on the 1744-wide layers; small grids were latency-bound).
+    struct Regs {
+        float4 a[NA], b[NB];
     };
-    auto fetch_tail = [&](int64_t k0) {
+    Regs r0, r1;
+    auto fetch_fast = [&](Regs& r, int64_t k0) {
 #pragma unroll
-        for (int c = 0; c < NA; ++c) ra[c] = load_k4<VEC, true>(pa[c] + k0, k0 + skq, K);
+        for (int c = 0; c < NA; ++c) r.a[c] = load_k4<VEC, false>(pa[c] + k0, 0, 0);
 #pragma unroll
-        for (int c = 0; c < NB; ++c) rb[c] = load_k4<VEC, true>(pw[c] + k0, k0 + skq, K);
+        for (int c = 0; c < NB; ++c) r.b[c] = load_k4<VEC, false>(pw[c] + k0, 0, 0);
     };
-    auto stash = [&](int buf) {
+    auto fetch_any = [&](Regs& r, int64_t k0) {       // prologue / last iterations only: full or ragged tile
+        if (k0 + KT <= K) {
+            fetch_fast(r, k0);
+        } else {
 #pragma unroll
-        for (int c = 0; c < NA; ++c) *reinterpret_cast<float4*>(As[buf] + (srow + RSTEP * c) * LD + skq) = ra[c];
+            for (int c = 0; c < NA; ++c) r.a[c] = load_k4<VEC, true>(pa[c] + k0, k0 + skq, K);
 #pragma unroll
-        for (int c = 0; c < NB; ++c) *reinterpret_cast<float4*>(Bs[buf] + (srow + RSTEP * c) * LD + skq) = rb[c];
+            for (int c = 0; c < NB; ++c) r.b[c] = load_k4<VEC, true>(pw[c] + k0, k0 + skq, K);
+        }
+    };
+    auto stash = [&](const Regs& r, int buf) {
+#pragma unroll
+        for (int c = 0; c < NA; ++c) *reinterpret_cast<float4*>(As[buf] + (srow + RSTEP * c) * LD + skq) = r.a[c];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) *reinterpret_cast<float4*>(Bs[buf] + (srow + RSTEP * c) * LD + skq) = r.b[c];
     };
 
     floatx4 acc[TM][TN];
@@ -131,30 +142,38 @@ k_linear(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t l
         }
     };
 
-    const int64_t nfull = K / KT;
-    const bool tail = (K % KT) != 0;
-    if (nfull > 0) fetch_fast(0); else fetch_tail(0);
-    stash(0);
+    const int64_t nfull = K / KT;                       // tiles loaded without guards
+    const int64_t T = (K + KT - 1) / KT;                // all tiles (the last one may be ragged)
+    // tile `it` lives in LDS buffer it&1; `cur` holds tile it+1 (in flight or landed), `nxt` receives tile it+2
+    auto step_fast = [&](int64_t it, Regs& cur, Regs& nxt) {
+        fetch_fast(nxt, (it + 2) * KT);
+        __builtin_amdgcn_sched_barrier(0);              // loads above the MFMAs, their first use below them
+        multiply((int)(it & 1));
+        __builtin_amdgcn_sched_barrier(0);
+        stash(cur, (int)((it + 1) & 1));                // that buffer was last read before the previous barrier
+        __syncthreads();
+    };
+    auto step_any = [&](int64_t it, Regs& cur, Regs& nxt) {
+        if (it + 2 < T) fetch_any(nxt, (it + 2) * KT);
+        multiply((int)(it & 1));
+        if (it + 1 < T) {
+            stash(cur, (int)((it + 1) & 1));
+            __syncthreads();
+        }
+    };
+    fetch_any(r0, 0);
+    stash(r0, 0);
     __syncthreads();
-    int buf = 0;
-    for (int64_t it = 0; it + 1 < nfull; ++it, buf ^= 1) {
-        fetch_fast((it + 1) * KT);
-        __builtin_amdgcn_sched_barrier(0);
-        multiply(buf);
-        __builtin_amdgcn_sched_barrier(0);
-        stash(buf ^ 1);
-        __syncthreads();
+    if (T > 1) fetch_any(r0, KT);
+    int64_t it = 0;
+    for (; it + 3 < nfull; it += 2) {                   // both steps prefetch full tiles (it+2, it+3 < nfull)
+        step_fast(it, r0, r1);
+        step_fast(it + 1, r1, r0);
     }
-    if (nfull > 0 && tail) {
-        fetch_tail(nfull * KT);
-        __builtin_amdgcn_sched_barrier(0);
-        multiply(buf);
-        __builtin_amdgcn_sched_barrier(0);
-        stash(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
+    for (; it < T; it += 2) {                           // the last few tiles, ragged one included
+        step_any(it, r0, r1);
+        if (it + 1 < T) step_any(it + 1, r1, r0);
     }
-    multiply(buf);
 
     // epilogue: D tile layout col = lane&15, row = 4*(lane>>4) + reg
 #pragma unroll

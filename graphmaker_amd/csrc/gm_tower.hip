@@ -136,8 +136,12 @@ int tower_layer(const TowerCtx& c, int l, const int32_t* rowptr, const int32_t* 
     float* agg = c.agg + r0 * c.ka;
     if (!c.d->is_mlp) {
         // GNNLayer.forward (:60-61): A @ [h_X | h_Y]; A @ h_Y is its last hY columns
-        GM_TRY(gm_spmm_mean(rows, rowptr + r0, colidx, hXl, ld, c.hX, agg, c.ka, c.stream));
-        GM_TRY(gm_spmm_mean(rows, rowptr + r0, colidx, hYl, ld, c.hY, agg + c.hX, c.ka, c.stream));
+        if (src) {   // gathered buffer: [h_X | h_Y] is one contiguous row, one launch covers both products
+            GM_TRY(gm_spmm_mean(rows, rowptr + r0, colidx, src, ld, c.hX + c.hY, agg, c.ka, c.stream));
+        } else {
+            GM_TRY(gm_spmm_mean(rows, rowptr + r0, colidx, hXl, ld, c.hX, agg, c.ka, c.stream));
+            GM_TRY(gm_spmm_mean(rows, rowptr + r0, colidx, hYl, ld, c.hY, agg + c.hX, c.ka, c.stream));
+        }
     } else {
         // MLPLayer.forward (:387-392): no aggregation, row-local
         GM_TRY(launch_copy2d(rows, c.hX, c.hcat + r0 * c.Hc + (int64_t)l * c.hX, c.Hc, agg, c.ka, c.s));
