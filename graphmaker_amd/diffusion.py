@@ -155,6 +155,15 @@ class BaseModel(nn.Module):
             cache[key] = torch.empty(shape, dtype=dtype, device=device)
         return cache[key]
 
+    def _const(self, key, host_array, device):
+        """Small per-step constants (time embedding input, posterior tables) uploaded once per (key, device) instead of
+        once per step: a pageable host-to-device copy stalls the launch stream of every step."""
+        cache = self.__dict__.setdefault("_consts", {})
+        k = (key, device)
+        if k not in cache:
+            cache[k] = torch.as_tensor(host_array).to(device)
+        return cache[k]
+
     def enable_phase_timing(self, on=True):
         self._prof = {} if on else None
 
@@ -287,7 +296,7 @@ class BaseModel(nn.Module):
         rows = None if plan is None else plan.node_range()
         with self.phase("tower_X"):
             logits = logits_fn(rows)
-        tabX_dev = torch.from_numpy(tab_X).to(dev)
+        tabX_dev = self._const(("tab_X", step, tab_X.tobytes()), tab_X, dev)
         if plan is None:
             with self.phase("attr"):
                 return ops.attr_posterior_sample(logits, x, tabX_dev, seed=seed, step=step, u=u)
@@ -384,7 +393,7 @@ class ModelSync(BaseModel):
         dev = x.device
         n = self.num_nodes
         tab_E, tab_X = self.step_tables(t)
-        t_float = torch.tensor([t / self.T], dtype=torch.float32).to(dev)      # :860
+        t_float = self._const(("t", t, self.T), np.array([t / self.T], np.float32), dev)   # :860
         uE = uniforms.get(("E", t)) if uniforms else None
         uX = uniforms.get(("X", t)) if uniforms else None
         if plan is not None:
@@ -423,7 +432,7 @@ class ModelSync(BaseModel):
                         stages.remove(g)
         h_on_wire = start(plan, h_pad, group)                        # node embeddings of every rank (pair kernel input)
         with self.phase("attr"):                                     # ... while this rank draws its attribute rows
-            ops.attr_posterior_sample(logits, x, torch.from_numpy(tab_X).to(dev), seed=seed, step=t, u=uX,
+            ops.attr_posterior_sample(logits, x, self._const(("tab_X", t, tab_X.tobytes()), tab_X, dev), seed=seed, step=t, u=uX,
                                       rows=plan.node_range(), x_s=x_pad[:n], want_onehot=False)
         x_on_wire = start(plan, x_pad, group)                        # travels under the pair kernel
         with self.phase("allgather_h"):
@@ -558,7 +567,7 @@ class ModelAsync(BaseModel):
     def attribute_step(self, t, x, x_onehot, Y32, seed, uniforms=None, plan=None, group=None):
         """Body of the loop at model/diffusion.py:1330-1358."""
         dev = x.device
-        t_float = torch.tensor([t / self.T_X], dtype=torch.float32).to(dev)
+        t_float = self._const(("tX", t, self.T_X), np.array([t / self.T_X], np.float32), dev)
         pred_X = self.graph_encoder.pred_X
         uX = uniforms.get(("X", t)) if uniforms else None
         return self._attribute_draw(self._logits_fn(pred_X, t_float, x_onehot, Y32, None, plan, group), x, self.table_X(t),
@@ -568,7 +577,7 @@ class ModelAsync(BaseModel):
     def structure_step(self, t, x_onehot, Y32, bits_t, seed, uniforms=None, plan=None, group=None):
         """Body of the loop at model/diffusion.py:1379-1401."""
         dev = x_onehot.device
-        t_float = torch.tensor([t / self.T_E], dtype=torch.float32).to(dev)
+        t_float = self._const(("tE", t, self.T_E), np.array([t / self.T_E], np.float32), dev)
         uE = uniforms.get(("E", t)) if uniforms else None
         _, bits_s = self._structure_step(self.graph_encoder.pred_E, t_float, x_onehot, Y32, bits_t, self.table_E(t), seed,
                                          t, u=uE, plan=plan, group=group)
