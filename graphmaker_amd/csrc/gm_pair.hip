@@ -60,6 +60,10 @@ struct PairArgs {
     uint32_t* counter;
     int ntj;
     int64_t ntiles;
+    // work items of the shared queue: items [0, nfull) are whole 64x64 tiles; the remaining tiles (fewer than one per
+    // workgroup) are handed out one row-unit per wave at a time (8 items per tile), so the last round of the queue
+    // does not leave most CUs idle for a whole tile time
+    int64_t nfull, nitems;
 };
 constexpr int MAXR = 4;
 
@@ -85,6 +89,16 @@ __device__ __forceinline__ void decode_tile(const PairArgs& a, int64_t t, int64_
 }
 
 // store a float4 of 4 consecutive k into the [even k | odd k] row image
+// queue item -> (tile, first unit, one-past-last unit)
+__device__ __forceinline__ void decode_item(const PairArgs& a, int64_t it, int64_t& tile, int& ub, int& ue) {
+    if (it < a.nfull) {
+        tile = it; ub = 0; ue = TILE / 8;
+    } else {
+        const int64_t r = it - a.nfull;
+        tile = a.nfull + (r >> 3); ub = (int)(r & 7); ue = ub + 1;
+    }
+}
+
 __device__ __forceinline__ void put_split(float* row, int c4, float4 v) {
     *reinterpret_cast<float2*>(row + 2 * c4) = make_float2(v.x, v.z);
     *reinterpret_cast<float2*>(row + 64 + 2 * c4) = make_float2(v.y, v.w);
@@ -196,10 +210,11 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
 #define STAMP() __builtin_readcyclecounter()
 #endif
 
-    while (t < a.ntiles) {
-        int64_t i0, j0, row_end;
-        int tj;
-        decode_tile(a, t, i0, j0, tj, row_end);
+    while (t < a.nitems) {
+        int64_t i0, j0, row_end, tile;
+        int tj, ub, ue;
+        decode_item(a, t, tile, ub, ue);
+        decode_tile(a, tile, i0, j0, tj, row_end);
 
         if (!staged) {   // first tile of this workgroup; later tiles are staged at the hand-over below
             stage_tile(a.h, a.n, i0, j0, hIs, hJs, tid);
@@ -210,7 +225,7 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
         // 8 row-units per wave and tile.  The two waves of a SIMD (w, w+4) alternate on the matrix pipe: group 0 runs
         // unit u, then group 1 runs unit u while group 0 does the VALU epilogue of its unit, and so on.  The turn is
         // handed over through turn_s[] in LDS (no data passes between the waves, only the right to issue MFMAs).
-        for (int u = 0; u < TILE / 8; ++u) {
+        for (int u = ub; u < ue; ++u) {
 #ifdef GM_PAIR_STAMP
             const unsigned long long ph0 = STAMP();
 #endif
@@ -364,10 +379,11 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
         if (tid == 0) *tile_s = (int)atomicAdd(a.counter, 1u);
         __syncthreads();
         t = *tile_s;
-        if (t < a.ntiles) {
-            int64_t ni0, nj0, nre;
-            int ntj_;
-            decode_tile(a, t, ni0, nj0, ntj_, nre);
+        if (t < a.nitems) {
+            int64_t ni0, nj0, nre, ntile;
+            int ntj_, nub, nue;
+            decode_item(a, t, ntile, nub, nue);
+            decode_tile(a, ntile, ni0, nj0, ntj_, nre);
             stage_tile(a.h, a.n, ni0, nj0, hIs, hJs, tid);
         }
         staged = true;
@@ -430,7 +446,9 @@ extern "C" int gm_pair_score_sample_ranges(int64_t n, int64_t hE, const float* h
     GM_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     GM_REQUIRE(cus > 0, "no compute units reported");
     GM_HIP(hipMemsetAsync(a.counter, 0, sizeof(uint32_t), s));
-    const unsigned grid = (unsigned)(a.ntiles < cus ? a.ntiles : cus);   // 137 KB of LDS: one workgroup per CU
+    a.nfull = (a.ntiles / cus) * cus;
+    a.nitems = a.nfull + 8 * (a.ntiles - a.nfull);
+    const unsigned grid = (unsigned)(a.nitems < cus ? a.nitems : cus);   // 137 KB of LDS: one workgroup per CU
     hipLaunchKernelGGL(k_pair_score_sample, dim3(grid), dim3(PAIR_THREADS), 0, s, a);
     GM_LAUNCH_CHECK();
     return GM_OK;
