@@ -231,6 +231,7 @@ def main():
     # a whole Sync sample (priors + all T reverse steps, free-running state) on all ranks, outside the timed steps
     full_sample_ms = None
     if not args.no_extras:
+        model.sample(seed=6, dense=False, plan=plan)       # untimed: first-use allocations of the trajectory's buffers
         barrier()
         t0 = time.perf_counter()
         model.sample(seed=7, dense=False, plan=plan)
