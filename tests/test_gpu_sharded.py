@@ -69,15 +69,45 @@ def _worker(rank, world, port, backend, name, q):
         dist.destroy_process_group()
 
 
-def _run(world, backend, name):
+def _worker_full(rank, world, port, backend, name, q):
+    """One whole reverse step at a BASELINE.json size (reference hidden sizes, random-init weights, prior-drawn state):
+    the sharded step of every rank must equal the single-GPU step bit for bit."""
+    import faulthandler
+    faulthandler.dump_traceback_later(150, exit=True)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        from graphmaker_amd import ops
+        from graphmaker_amd.parallel import ShardPlan
+        wl = dict(bench.WORKLOAD, name="amazon_photo", N=7650, F=745, C=8, density=4.07e-3)      # SURVEY.md section 8 table
+        model = bench.build_model(wl, dev)
+        n, T = wl["N"], wl["T"]
+        Em = model.transition.E_marginal_host
+        Y32 = ops.prior_Y(n, model.Y_marginal, seed=3)
+        bits = ops.prior_E(n, float(Em[0]), float(Em[1]), dev, seed=3)
+        x, oh = ops.prior_X(n, model.X_marginal, seed=3)
+        want = model.denoise_step(T, x, oh, Y32, bits, seed=5)
+        got = model.denoise_step(T, x, oh, Y32, bits, seed=5, plan=ShardPlan.make(n, world, rank))
+        torch.cuda.synchronize()
+        q.put((rank, _same(want, got), True, int(want[2].ne(0).sum().item())))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, backend, name, worker=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, name, q)) for r in range(world)]
+    procs = [ctx.Process(target=worker or _worker, args=(r, world, port, backend, name, q)) for r in range(world)]
     for p in procs:
         p.start()
     try:
-        res = [q.get(timeout=70) for _ in range(world)]
+        res = [q.get(timeout=160 if worker else 70) for _ in range(world)]
         for p in procs:
             p.join(timeout=60)
             assert p.exitcode == 0
@@ -100,3 +130,8 @@ def test_sharded_sample_ranks_share_one_gpu(world, name):
 @pytest.mark.parametrize("name", ["sync_mid", "async_mid"])
 def test_sharded_sample_one_rank_rccl(name):
     _run(1, "nccl", name)
+
+
+def test_sharded_step_amazon_photo_size_two_ranks():
+    """BASELINE.json configs[2]: amazon_photo (7650 nodes, 745 attributes) on 1 and 2 GPUs -- here both ranks on one."""
+    _run(2, "gloo", "amazon_photo", worker=_worker_full)
