@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libgraphmaker_hip.so")
 # every symbol include/graphmaker_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
     "gm_version", "gm_last_error", "gm_device_cus",
-    "gm_bitmap_from_dense_i64", "gm_dense_i64_from_bitmap", "gm_symmetrize_upper", "gm_csr_rowptr", "gm_csr_fill",
+    "gm_bitmap_from_dense_i64", "gm_dense_i64_from_bitmap", "gm_symmetrize_upper", "gm_csr_rowptr", "gm_csr_rowptr_capped", "gm_csr_fill",
     "gm_bitmap_from_upper_edges", "gm_spmm_mean", "gm_linear", "gm_layernorm", "gm_tower_workspace_bytes",
     "gm_tower_forward", "gm_tower_stage", "gm_hadamard_gather", "gm_pair_score_sample", "gm_pair_score_sample_ranges", "gm_attr_posterior_sample", "gm_onehot_from_x",
     "gm_x_from_onehot", "gm_prior_Y", "gm_prior_X", "gm_prior_E",

@@ -126,6 +126,19 @@ __global__ void k_exclusive_scan(int64_t n, int32_t* __restrict__ rowptr) {
     if (tid == 0) rowptr[n] = carry_s;
 }
 
+// rowptr[0..n] = min(rowptr, capacity); *overflow |= (rowptr[n] > capacity).  With a caller-owned colidx buffer of fixed
+// capacity no host read of the edge count is needed: every consumer of (rowptr, colidx) stays inside the buffer, and
+// the flag tells the host later that a result built on the truncated list must be discarded.
+__global__ void k_clamp_rowptr(int64_t n, int64_t capacity, int32_t* __restrict__ rowptr, int32_t* __restrict__ overflow) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx > n) return;
+    const int64_t v = rowptr[idx];
+    if (v > capacity) {
+        rowptr[idx] = (int32_t)capacity;
+        if (idx == n) atomicOr(overflow, 1);
+    }
+}
+
 // column indices in ascending order: one wave per row, lanes take words, in-wave prefix of popcounts
 __global__ void k_csr_fill(int64_t n, int64_t wpr, const uint32_t* __restrict__ bits, int upper_only,
                            const int32_t* __restrict__ rowptr, int64_t capacity, int32_t* __restrict__ colidx,
@@ -212,6 +225,16 @@ extern "C" int gm_csr_rowptr(int64_t n, int64_t wpr, const uint32_t* bits, int u
     hipLaunchKernelGGL(k_row_degree, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, as_stream(stream), n, wpr, bits, upper_only, rowptr);
     GM_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, as_stream(stream), n, rowptr);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+extern "C" int gm_csr_rowptr_capped(int64_t n, int64_t wpr, const uint32_t* bits, int upper_only, int64_t capacity,
+                                    int32_t* rowptr, int32_t* overflow, gm_stream_t stream) {
+    GM_REQUIRE(capacity > 0 && capacity < (1ll << 31) && overflow, "bad capacity or null overflow flag");
+    if (int rc = gm_csr_rowptr(n, wpr, bits, upper_only, rowptr, stream)) return rc;
+    hipLaunchKernelGGL(k_clamp_rowptr, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, as_stream(stream), n, capacity, rowptr,
+                       overflow);
     GM_LAUNCH_CHECK();
     return GM_OK;
 }

@@ -164,6 +164,13 @@ class BaseModel(nn.Module):
             cache[k] = torch.as_tensor(host_array).to(device)
         return cache[k]
 
+    def _csr_ws(self, device):
+        """The step-local adjacency workspace (ops.CsrWorkspace) of this model on `device`."""
+        ws = self.__dict__.get("_csr_workspace")
+        if ws is None or ws.device != device or ws.n != self.num_nodes:
+            ws = self.__dict__["_csr_workspace"] = ops.CsrWorkspace(self.num_nodes, device)
+        return ws
+
     def enable_phase_timing(self, on=True):
         self._prof = {} if on else None
 
@@ -248,8 +255,8 @@ class BaseModel(nn.Module):
         """get_E_t (model/diffusion.py:428-472): returns (A_t, symmetric bitmap of E_s).
         plan: parallel.ShardPlan for the one-process-per-GPU decomposition (None = single GPU)."""
         n = self.num_nodes
-        with self.phase("csr"):
-            A_t = ops.adjacency_from_bitmap(bits_t, n)
+        with self.phase("csr"):      # built into the model's workspace: no host read of the edge count in a step
+            A_t = ops.adjacency_from_bitmap(bits_t, n, workspace=self._csr_ws(bits_t.device))
         enc = pred_E.gnn_encoder
         with self.phase("tower_E"):
             if plan is None:
@@ -311,6 +318,8 @@ class BaseModel(nn.Module):
 
     def _finish(self, x_onehot, Y32, bits, dense):
         n, Fa = self.num_nodes, self.num_attrs_X
+        if self.__dict__.get("_csr_workspace") is not None:
+            self._csr_workspace.check()                                     # the one host read of a trajectory
         X = torch.transpose(x_onehot.reshape(n, Fa, -1), 0, 1)             # model/diffusion.py:899-901
         Y_one_hot = F.one_hot(Y32.long(), num_classes=self.num_classes_Y).float()
         if dense:
@@ -416,7 +425,7 @@ class ModelSync(BaseModel):
         ge = self.graph_encoder
         enc, pred_X = ge.pred_E.gnn_encoder, ge.pred_X
         with self.phase("csr"):
-            A_t = ops.adjacency_from_bitmap(bits_t, n)
+            A_t = ops.adjacency_from_bitmap(bits_t, n, workspace=self._csr_ws(dev))
         h_pad = self._buf("h_pad", (plan.world * plan.node_rows, enc._dims.out_size), torch.float32, dev)
         logits = self._buf("logits", (n, pred_X._dims.out_size), torch.float32, dev)
         x_pad = self._buf("x_pad", (plan.world * plan.node_rows, x.shape[1]), torch.uint8, dev)

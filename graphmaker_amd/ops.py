@@ -12,8 +12,9 @@ class Adjacency:
     """What get_adj (model/diffusion.py:239-256) returns here: the row-normalised adjacency D^-1 A in CSR form with
     implicit values 1/deg[row], plus the symmetric bitmap it was built from."""
 
-    def __init__(self, n, bits, rowptr, colidx):
+    def __init__(self, n, bits, rowptr, colidx, nnz=None):
         self.n, self.bits, self.rowptr, self.colidx = n, bits, rowptr, colidx
+        self._nnz = nnz
 
     @property
     def shape(self):
@@ -21,7 +22,11 @@ class Adjacency:
 
     @property
     def nnz(self):
-        return int(self.colidx.numel())
+        """Directed non-zeros.  An adjacency built into a CsrWorkspace has not read its edge count back yet: the first
+        use of this property is a device-to-host read."""
+        if self._nnz is None:
+            self._nnz = int(self.rowptr[self.n].item())
+        return self._nnz
 
     def __matmul__(self, H):
         """A @ H (model/gnn.py:60-61)."""
@@ -68,9 +73,38 @@ def csr_from_bitmap(bits, n, upper_only=False, want_rows=False):
     return rowptr, colidx[:nnz]
 
 
-def adjacency_from_bitmap(bits, n):
-    rowptr, colidx = csr_from_bitmap(bits, n)
-    return Adjacency(n, bits, rowptr, colidx)
+class CsrWorkspace:
+    """A colidx buffer of fixed capacity that the reverse steps of one model build their adjacency into, so that no step
+    has to read the edge count back to size an allocation (gm_csr_rowptr_capped).  Up to 16384 nodes the capacity is n*n
+    (no graph can overflow it); beyond, 2^28 entries (1 GiB), and `overflow` tells after the fact that a denser graph was
+    truncated -- check() raises then.  One adjacency at a time lives in it: callers that keep several use the exact path."""
+
+    def __init__(self, n, device):
+        self.capacity = int(min(n * n, 1 << 28))
+        self.colidx = torch.empty(self.capacity, dtype=torch.int32, device=device)
+        self.overflow = torch.zeros(1, dtype=torch.int32, device=device)
+        self.n, self.device = n, device
+
+    def check(self):
+        if int(self.overflow.item()):
+            self.overflow.zero_()
+            raise RuntimeError(f"a sampled graph has more than {self.capacity} directed edges: the step-local adjacency was "
+                               "truncated and the sample is invalid (graphs this dense need the exact-size CSR path)")
+
+
+def adjacency_from_bitmap(bits, n, workspace=None):
+    """get_adj on the library's bitmap state.  workspace: a CsrWorkspace -> no host synchronisation (the step path)."""
+    if workspace is None:
+        rowptr, colidx = csr_from_bitmap(bits, n)
+        return Adjacency(n, bits, rowptr, colidx, nnz=int(colidx.numel()))
+    require(bits, torch.int32, "bits")
+    wpr = bits.shape[1]
+    rowptr = torch.empty(n + 1, dtype=torch.int32, device=bits.device)
+    L.call("gm_csr_rowptr_capped", I64(n), I64(wpr), ptr(bits), I32(0), I64(workspace.capacity), ptr(rowptr),
+           ptr(workspace.overflow), stream_ptr())
+    L.call("gm_csr_fill", I64(n), I64(wpr), ptr(bits), I32(0), ptr(rowptr), I64(workspace.capacity), ptr(workspace.colidx),
+           None, stream_ptr())
+    return Adjacency(n, bits, rowptr, workspace.colidx)
 
 
 def bitmap_from_upper_edges(n, ei, ej):

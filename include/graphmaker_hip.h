@@ -65,6 +65,13 @@ int gm_symmetrize_upper(int64_t n, int64_t wpr, const uint32_t* upper, uint32_t*
  *   gm_csr_rowptr  : rowptr[0..n]           (workspace: none)
  *   gm_csr_fill    : colidx[0..rowptr[n])   (caller read rowptr[n] to size it, or passes capacity >= nnz) */
 int gm_csr_rowptr(int64_t n, int64_t wpr, const uint32_t* bits, int upper_only, int32_t* rowptr, gm_stream_t stream);
+/* gm_csr_rowptr for a caller-owned colidx buffer of `capacity` entries: the row pointers are clamped to the capacity and
+ * *overflow (device int32, caller-zeroed once) is OR-ed with 1 when the graph has more entries.  Followed by gm_csr_fill
+ * with the same capacity it builds the adjacency of get_adj (model/diffusion.py:239-256) with no host read of the edge
+ * count, so consecutive reverse steps can be enqueued without a device-to-host synchronisation; the caller reads the
+ * flag once per sample and discards the sample if it is set. */
+int gm_csr_rowptr_capped(int64_t n, int64_t wpr, const uint32_t* bits, int upper_only, int64_t capacity,
+                         int32_t* rowptr, int32_t* overflow, gm_stream_t stream);
 int gm_csr_fill(int64_t n, int64_t wpr, const uint32_t* bits, int upper_only, const int32_t* rowptr,
                 int64_t capacity, int32_t* colidx, int32_t* rows, gm_stream_t stream);
 /* edge list (i<j) -> symmetric bitmap (multi-GPU gather path; model/diffusion.py:423-424) */

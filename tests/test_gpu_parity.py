@@ -354,6 +354,33 @@ def test_pair_kernel_large_against_oracle_rows_and_sharding(dev):
     assert torch.equal(dense, dense.T) and int(dense.diagonal().sum()) == 0
 
 
+def test_capped_csr_matches_exact_and_flags_overflow(dev):
+    """The step-local adjacency (no host read of the edge count) equals get_adj's CSR; a too-small buffer is truncated
+    in bounds and reported."""
+    ops = _ops()
+    n = 777
+    _, bits = random_sym_bits(n, 0.02, 9)
+    b = bits_t(bits, dev)
+    exact = ops.adjacency_from_bitmap(b, n)
+    ws = ops.CsrWorkspace(n, dev)
+    capped = ops.adjacency_from_bitmap(b, n, workspace=ws)
+    assert torch.equal(capped.rowptr, exact.rowptr) and capped.nnz == exact.nnz
+    assert torch.equal(capped.colidx[:exact.nnz], exact.colidx)
+    H = torch.randn(n, 96, device=dev)
+    assert torch.equal(ops.spmm_mean(capped, H), ops.spmm_mean(exact, H))
+    ws.check()                                                # no overflow
+    small = ops.CsrWorkspace(n, dev)
+    small.capacity = exact.nnz // 2
+    small.colidx = torch.full((small.capacity + 64,), -7, dtype=torch.int32, device=dev)
+    trunc = ops.adjacency_from_bitmap(b, n, workspace=small)
+    assert int(trunc.rowptr.max()) == small.capacity
+    assert torch.equal(trunc.colidx[:small.capacity], exact.colidx[:small.capacity])
+    assert bool((small.colidx[small.capacity:] == -7).all())  # nothing written past the capacity
+    ops.spmm_mean(trunc, H)                                   # consumers stay inside the buffer
+    with pytest.raises(RuntimeError):
+        small.check()
+
+
 def test_no_fallback_on_cpu_tensors():
     from graphmaker_amd import ops
     from graphmaker_amd._lib import GraphMakerHipError
