@@ -45,9 +45,11 @@ k_symmetrize(int64_t n, int64_t wpr, const uint32_t* __restrict__ upper, uint32_
     const int64_t i = I * 32 + li;
     const int wavesPerBlock = blockDim.x >> 6;
     const int wv = threadIdx.x >> 6;
-    const int64_t wsteps = (wpr + 2 * wavesPerBlock - 1) / (2 * wavesPerBlock);
+    // blockIdx.y interleaves the word range over gridDim.y blocks (a row tile alone is too little latency-bound work per CU)
+    const int64_t per_it = 2 * wavesPerBlock * (int64_t)gridDim.y;
+    const int64_t wsteps = (wpr + per_it - 1) / per_it;
     for (int64_t it = 0; it < wsteps; ++it) {            // uniform trip count: the ballots need every lane
-        const int64_t w = it * 2 * wavesPerBlock + wv * 2 + half;
+        const int64_t w = (it * gridDim.y + blockIdx.y) * 2 * wavesPerBlock + wv * 2 + half;
         const bool inw = w < wpr;
         uint32_t own = 0, src = 0;
         if (inw && i < n && w >= I && w * 32 < n) {
@@ -214,7 +216,10 @@ extern "C" int gm_symmetrize_upper(int64_t n, int64_t wpr, const uint32_t* upper
     if (int rc = check_bitmap_args(n, wpr)) return rc;
     GM_REQUIRE(upper && sym && upper != sym, "null or aliased pointer");
     const int64_t tiles = (n + 31) / 32;
-    hipLaunchKernelGGL(k_symmetrize, dim3((unsigned)tiles), dim3(256), 0, as_stream(stream), n, wpr, upper, sym);
+    int64_t split = (4096 + tiles - 1) / tiles;          // ~4096 workgroups
+    if (split > (wpr + 7) / 8) split = (wpr + 7) / 8;
+    if (split < 1) split = 1;
+    hipLaunchKernelGGL(k_symmetrize, dim3((unsigned)tiles, (unsigned)split), dim3(256), 0, as_stream(stream), n, wpr, upper, sym);
     GM_LAUNCH_CHECK();
     return GM_OK;
 }
