@@ -116,7 +116,13 @@ def test_spmm_mean(dev, n, d, density):
 
 @pytest.mark.parametrize("M,N,K,relu,bias", [(1, 16, 1, True, True), (67, 32, 22, True, True), (200, 304, 304, True, True),
                                              (130, 128, 152, False, True), (257, 40, 131, False, False),
-                                             (300, 1534, 1744, False, True)])
+                                             (300, 1534, 1744, False, True),
+                                             # 64x64 configuration: k shorter than a k-tile, odd / even-only leading
+                                             # dimensions (scalar and float2 loaders), one ragged k-tile after full ones
+                                             (70, 65, 3, True, True), (129, 130, 33, False, True), (64, 64, 98, True, True),
+                                             (1, 1, 4097, False, True),
+                                             # 128x128 / 8-wave configuration (>= 400 tiles) with ragged edges in M, N, K
+                                             (3000, 2310, 70, True, True), (2700, 2400, 37, False, False)])
 def test_linear(dev, M, N, K, relu, bias):
     ops = _ops()
     rs = np.random.RandomState(M + N + K)
