@@ -387,6 +387,34 @@ def test_capped_csr_matches_exact_and_flags_overflow(dev):
         small.check()
 
 
+@pytest.mark.parametrize("N,F,C,density", [(2, 1, 1, 0.5), (3, 2, 2, 0.9), (33, 1, 5, 0.2), (65, 3, 1, 0.0), (129, 5, 3, 1.0)])
+def test_degenerate_sizes_whole_sample_bit_identical_to_oracle(dev, N, F, C, density):
+    """Smallest and ragged shapes (two nodes, one attribute, one class, an empty and a complete prior graph, sizes one
+    past a 32 / 64 / 128 boundary): the whole Sync sample equals the oracle's bit for bit."""
+    import graphmaker_amd as gm
+    cfg = dict(variant="Sync", N=N, F=F, C=C, T=2, density=density, seed=100 + N,
+               gnn_X=dict(hidden_t=4, hidden_X=8, hidden_Y=4, num_gnn_layers=1, dropout=0.0),
+               gnn_E=dict(hidden_t=4, hidden_X=8, hidden_Y=4, hidden_E=128, num_gnn_layers=1, dropout=0.0))
+    Xm, Ym, Em = gu.marginals(cfg)
+    sdX, sdE = gu.make_checkpoint(cfg, edge_bias=0.3, attr_bias=0.2)
+    model = gm.ModelSync(T=cfg["T"], X_marginal=t_(Xm, dev), Y_marginal=t_(Ym, dev), E_marginal=t_(Em, dev),
+                         gnn_X_config=cfg["gnn_X"], gnn_E_config=cfg["gnn_E"], num_nodes=N)
+    model.graph_encoder.pred_X.load_state_dict({k: torch.from_numpy(v) for k, v in sdX.items()})
+    model.graph_encoder.pred_E.load_state_dict({k: torch.from_numpy(v) for k, v in sdE.items()})
+    model = model.to(dev).eval()
+    X, Y1h, E = model.sample(seed=cfg["seed"])
+    towerX = orc.Tower.from_state_dict(sdX, is_mlp=False)
+    towerE = orc.Tower.from_state_dict(sdE, is_mlp=False, prefix="gnn_encoder.")
+    pair = orc.PairMLP(sdE["mlp_out.0.weight"], sdE["mlp_out.0.bias"], sdE["mlp_out.2.weight"], sdE["mlp_out.2.bias"])
+    ns = model.noise_schedule
+    x, y, bits = orc.sample_sync(cfg["T"], N, Xm, Ym, Em, towerX, towerE, pair, cfg["seed"],
+                                 sched=(ns.alphas_host, ns.alpha_bars_host))
+    np.testing.assert_array_equal(Y1h.argmax(1).cpu().numpy(), y)
+    np.testing.assert_array_equal(X[:, :, 1].T.cpu().numpy().astype(np.uint8), x)
+    np.testing.assert_array_equal(E.cpu().numpy(), orc.dense_from_bitmap(bits, N))
+    assert X.shape == (F, N, 2) and Y1h.shape == (N, C) and E.shape == (N, N)
+
+
 def test_no_fallback_on_cpu_tensors():
     from graphmaker_amd import ops
     from graphmaker_amd._lib import GraphMakerHipError
