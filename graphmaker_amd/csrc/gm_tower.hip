@@ -118,8 +118,10 @@ int tower_input(const TowerCtx& c, const float* t_float, const float* X_one_hot,
     const int64_t in_X = c.d->in_X;
     GM_TRY(launch_broadcast_row(rows, c.ht, c.ht1, c.hcat + r0 * c.Hc + c.offT, c.Hc, c.s));
     GM_TRY(launch_broadcast_row(rows, c.ht, c.ht1, c.agg + r0 * c.ka + c.hX + c.hY, c.ka, c.s));
-    GM_TRY(gm_linear(rows, c.hX, in_X, X_one_hot + r0 * in_X, in_X, P[4], in_X, P[5], c.tmpX + r0 * c.hX, c.hX, 1, c.stream));
-    GM_TRY(gm_linear(rows, c.hX, c.hX, c.tmpX + r0 * c.hX, c.hX, P[6], c.hX, P[7], c.hcat + r0 * c.Hc, c.Hc, 1, c.stream));
+    if (X_one_hot) {   // NULL: h_X^0 of these rows is still in the workspace from the previous call with the same X
+        GM_TRY(gm_linear(rows, c.hX, in_X, X_one_hot + r0 * in_X, in_X, P[4], in_X, P[5], c.tmpX + r0 * c.hX, c.hX, 1, c.stream));
+        GM_TRY(gm_linear(rows, c.hX, c.hX, c.tmpX + r0 * c.hX, c.hX, P[6], c.hX, P[7], c.hcat + r0 * c.Hc, c.Hc, 1, c.stream));
+    }
     GM_TRY(launch_gather_rows(rows, c.hY, Y + r0, P[8], c.hY, c.hcat + r0 * c.Hc + c.offY, c.Hc, c.s));
     return GM_OK;
 }
@@ -175,7 +177,7 @@ extern "C" int gm_tower_forward(const gm_tower_dims* d, const float* const* P, i
                                 size_t workspace_bytes, gm_stream_t stream) {
     TowerCtx c;
     if (int rc = tower_ctx(c, d, P, n, workspace, workspace_bytes, stream)) return rc;
-    GM_REQUIRE(t_float && X_one_hot && Y && out, "null pointer");
+    GM_REQUIRE(t_float && Y && out, "null pointer");
     GM_REQUIRE(d->is_mlp || d->num_layers == 0 || (rowptr && colidx), "GNN tower needs a CSR adjacency");
     GM_REQUIRE(0 <= out_row_begin && out_row_begin <= out_row_end && out_row_end <= n, "bad output row range [%lld,%lld)",
                (long long)out_row_begin, (long long)out_row_end);
@@ -196,7 +198,7 @@ extern "C" int gm_tower_stage(const gm_tower_dims* d, const float* const* P, int
                (long long)row_end);
     GM_REQUIRE(stage >= -1 && stage <= c.nl, "stage %d out of range [-1,%d]", stage, c.nl);
     if (stage == -1) {
-        GM_REQUIRE(t_float && X_one_hot && Y, "null pointer");
+        GM_REQUIRE(t_float && Y, "null pointer");
         GM_TRY(tower_input(c, t_float, X_one_hot, Y, row_begin, row_end));
     } else if (stage < c.nl) {
         GM_REQUIRE(d->is_mlp || (rowptr && colidx), "GNN tower needs a CSR adjacency");

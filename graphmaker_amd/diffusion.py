@@ -251,20 +251,23 @@ class BaseModel(nn.Module):
                                f"cuda first (got {dev}).  There is no CPU path.")
         return dev
 
-    def _structure_step(self, pred_E, t_float, X_one_hot, Y32, bits_t, tab_E, seed, step, u=None, plan=None, group=None):
+    def _structure_step(self, pred_E, t_float, X_one_hot, Y32, bits_t, tab_E, seed, step, u=None, plan=None, group=None,
+                        reuse_X=False):
         """get_E_t (model/diffusion.py:428-472): returns (A_t, symmetric bitmap of E_s).
-        plan: parallel.ShardPlan for the one-process-per-GPU decomposition (None = single GPU)."""
+        plan: parallel.ShardPlan for the one-process-per-GPU decomposition (None = single GPU).
+        reuse_X: X_one_hot is the tensor of the previous call (ModelAsync's structure steps): mlp_in_X(X) is not recomputed."""
         n = self.num_nodes
         with self.phase("csr"):      # built into the model's workspace: no host read of the edge count in a step
             A_t = ops.adjacency_from_bitmap(bits_t, n, workspace=self._csr_ws(bits_t.device))
         enc = pred_E.gnn_encoder
         with self.phase("tower_E"):
             if plan is None:
-                h = enc(t_float, X_one_hot, Y32, A_t)
+                h = enc._run(t_float, X_one_hot, Y32, A_t, reuse_X=reuse_X)
             else:
                 h_pad = self._buf("h_pad", (plan.world * plan.node_rows, enc._dims.out_size), torch.float32,
                                   X_one_hot.device)
-                enc._run_sharded(t_float, X_one_hot, Y32, A_t, plan, group, h_pad[:n], parallel.all_gather_node_rows)
+                enc._run_sharded(t_float, X_one_hot, Y32, A_t, plan, group, h_pad[:n], parallel.all_gather_node_rows,
+                                 reuse_X=reuse_X)
         if plan is not None:
             with self.phase("allgather_h"):
                 h = parallel.all_gather_node_rows(plan, h_pad, group)[:n]
@@ -583,13 +586,14 @@ class ModelAsync(BaseModel):
                                     seed, t, u=uX, plan=plan, group=group)
 
     @torch.no_grad()
-    def structure_step(self, t, x_onehot, Y32, bits_t, seed, uniforms=None, plan=None, group=None):
-        """Body of the loop at model/diffusion.py:1379-1401."""
+    def structure_step(self, t, x_onehot, Y32, bits_t, seed, uniforms=None, plan=None, group=None, reuse_X=False):
+        """Body of the loop at model/diffusion.py:1379-1401.  reuse_X: x_onehot is unchanged since the previous structure
+        step of this model (the steps condition on the final attributes), so its input projection is kept."""
         dev = x_onehot.device
         t_float = self._const(("tE", t, self.T_E), np.array([t / self.T_E], np.float32), dev)
         uE = uniforms.get(("E", t)) if uniforms else None
         _, bits_s = self._structure_step(self.graph_encoder.pred_E, t_float, x_onehot, Y32, bits_t, self.table_E(t), seed,
-                                         t, u=uE, plan=plan, group=group)
+                                         t, u=uE, plan=plan, group=group, reuse_X=reuse_X)
         return bits_s
 
     @torch.no_grad()
@@ -606,5 +610,7 @@ class ModelAsync(BaseModel):
             x, x_onehot = self.attribute_step(s_X + 1, x, x_onehot, Y32, seed, uniforms=uni, plan=plan, group=group)
         bits = ops.prior_E(n, float(Em[0]), float(Em[1]), dev, seed=seed, u=uni.get("E_prior"))        # :1362-1365
         for s_E in reversed(range(0, self.T_E)):                                                        # :1379
-            bits = self.structure_step(s_E + 1, x_onehot, Y32, bits, seed, uniforms=uni, plan=plan, group=group)
+            # every structure step conditions on the final attributes: their input projection is computed once (s_E = T_E-1)
+            bits = self.structure_step(s_E + 1, x_onehot, Y32, bits, seed, uniforms=uni, plan=plan, group=group,
+                                       reuse_X=s_E != self.T_E - 1)
         return self._finish(x_onehot, Y32, bits, dense)

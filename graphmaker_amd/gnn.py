@@ -82,6 +82,7 @@ class _TowerBase(nn.Module):
         need = ops.tower_workspace_bytes(self._dims, n)
         if self._ws is None or self._ws.numel() < need or self._ws.device != device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+            self._hx0_rows = None                  # a fresh workspace holds no mlp_in_X(X) to reuse
         return self._ws
 
     def _on_tape(self):
@@ -120,7 +121,9 @@ class _TowerBase(nn.Module):
         h_cat = torch.cat(hX_list + hY_list + [h_t_exp], dim=1)
         return lin(self.mlp_out[2], lin(self.mlp_out[0], h_cat, True), False)
 
-    def _run(self, t_float, X_t_one_hot, Y_real, A_t, want_hcat=False, rows=None, out=None):
+    def _run(self, t_float, X_t_one_hot, Y_real, A_t, want_hcat=False, rows=None, out=None, reuse_X=False):
+        """reuse_X: the caller guarantees that X_t_one_hot, the parameters and the node count are those of the previous
+        fused call of THIS tower, so mlp_in_X(X) is taken from the tower's workspace (ModelAsync's structure steps)."""
         if self._on_tape() and not want_hcat and rows is None and out is None:
             return self._run_tape(t_float, X_t_one_hot, Y_real, A_t)
         if self.training and any(m.p > 0 for m in self.modules() if isinstance(m, nn.Dropout)):
@@ -129,11 +132,14 @@ class _TowerBase(nn.Module):
         X = X_t_one_hot if X_t_one_hot.is_contiguous() else X_t_one_hot.contiguous()
         Y32 = Y_real if Y_real.dtype == torch.int32 else Y_real.to(torch.int32)
         t = t_float.reshape(1).to(torch.float32)
-        return ops.tower_forward(self._dims, self._param_ptrs(), n, t, X, Y32.contiguous(), A_t,
-                                 self._workspace(n, X.device), want_hcat=want_hcat, rows=rows, out=out)
+        ws = self._workspace(n, X.device)
+        reuse = reuse_X and getattr(self, "_hx0_rows", None) == (n, None)
+        self._hx0_rows = (n, None)
+        return ops.tower_forward(self._dims, self._param_ptrs(), n, t, None if reuse else X, Y32.contiguous(), A_t, ws,
+                                 want_hcat=want_hcat, rows=rows, out=out)
 
 
-    def _run_sharded(self, t_float, X_t_one_hot, Y_real, A_t, plan, group, out, gather):
+    def _run_sharded(self, t_float, X_t_one_hot, Y_real, A_t, plan, group, out, gather, reuse_X=False):
         """Row-sharded forward for the one-process-per-GPU decomposition: this rank computes node rows
         plan.node_range() of every stage; before each message-passing layer the [h_X | h_Y] rows of all ranks are
         replicated by `gather` (parallel.all_gather_node_rows).  Writes rows node_range() of `out` (n, out_size)."""
@@ -143,11 +149,11 @@ class _TowerBase(nn.Module):
 
             def wait(self):
                 pass
-        for _ in self._sharded_stages(t_float, X_t_one_hot, Y_real, A_t, plan, group, out, _Now):
+        for _ in self._sharded_stages(t_float, X_t_one_hot, Y_real, A_t, plan, group, out, _Now, reuse_X=reuse_X):
             pass
         return out
 
-    def _sharded_stages(self, t_float, X_t_one_hot, Y_real, A_t, plan, group, out, gather_start):
+    def _sharded_stages(self, t_float, X_t_one_hot, Y_real, A_t, plan, group, out, gather_start, reuse_X=False):
         """_run_sharded as a generator: it yields right after each all-gather has been STARTED
         (gather_start(plan, buffer, group) -> handle with .wait(), parallel.start_all_gather_node_rows) and waits for it
         when resumed, so the caller can enqueue other kernels (the other tower's stage) under the transfer."""
@@ -155,15 +161,19 @@ class _TowerBase(nn.Module):
         X = X_t_one_hot if X_t_one_hot.is_contiguous() else X_t_one_hot.contiguous()
         Y32 = (Y_real if Y_real.dtype == torch.int32 else Y_real.to(torch.int32)).contiguous()
         t = t_float.reshape(1).to(torch.float32)
-        d, ptrs, ws = self._dims, self._param_ptrs(), self._workspace(n, X.device)
+        dev = X.device
+        d, ptrs, ws = self._dims, self._param_ptrs(), self._workspace(n, dev)
         rows = plan.node_range()
+        if reuse_X and getattr(self, "_hx0_rows", None) == (n, rows):
+            X = None                               # mlp_in_X(X) of these rows is still in the workspace
+        self._hx0_rows = (n, rows)
         need_gather = not self._is_mlp and d.num_layers > 0
         width = d.hidden_X + d.hidden_Y
         bufs = [None, None]
         if need_gather:   # persistent across steps: the collectives' stream keeps references, re-allocating churns
-            key = (plan.world * plan.node_rows, width, X.device)
+            key = (plan.world * plan.node_rows, width, dev)
             if getattr(self, "_gather_key", None) != key:
-                self._gather_bufs = [torch.empty(key[:2], dtype=torch.float32, device=X.device) for _ in range(2)]
+                self._gather_bufs = [torch.empty(key[:2], dtype=torch.float32, device=dev) for _ in range(2)]
                 self._gather_key = key
             bufs = self._gather_bufs
         ops.tower_stage(d, ptrs, n, -1, rows, ws, t_float=t, X_one_hot=X, Y32=Y32, layer_dst=bufs[0])

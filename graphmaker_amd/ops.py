@@ -153,12 +153,14 @@ def tower_workspace_bytes(dims, n):
 
 
 def tower_forward(dims, param_ptrs, n, t_float, X_one_hot, Y32, adj, workspace, out=None, want_hcat=False, rows=None):
+    """X_one_hot=None: reuse mlp_in_X(X) left in `workspace` by the previous call (same attributes, see the header)."""
     require(t_float, torch.float32, "t_float")
-    require(X_one_hot, torch.float32, "X_t_one_hot")
     require(Y32, torch.int32, "Y")
-    if X_one_hot.shape != (n, dims.in_X):
-        raise ValueError(f"X_t_one_hot is {tuple(X_one_hot.shape)}, expected {(n, dims.in_X)}")
-    dev = X_one_hot.device
+    if X_one_hot is not None:
+        require(X_one_hot, torch.float32, "X_t_one_hot")
+        if X_one_hot.shape != (n, dims.in_X):
+            raise ValueError(f"X_t_one_hot is {tuple(X_one_hot.shape)}, expected {(n, dims.in_X)}")
+    dev = Y32.device
     if out is None:
         out = torch.empty((n, dims.out_size), dtype=torch.float32, device=dev)
     hcat = torch.empty((n, dims.hidden_cat), dtype=torch.float32, device=dev) if want_hcat else None

@@ -98,7 +98,10 @@ int gm_layernorm(int64_t M, int64_t N, float* X, int64_t ldx, const float* gamma
  * out: (n, out_size) row-major.  hcat_out: optional (n, hidden_cat) copy of the concatenated hidden state.
  * [out_row_begin, out_row_end): rows of `out` to produce.  The graph part of the tower always runs on all n nodes
  * (message passing needs every row); the row-independent output MLP (model/gnn.py:138-142), most of the FLOPs,
- * runs only on this range, which is how one tower is sharded over GPUs (pass 0, n for everything). */
+ * runs only on this range, which is how one tower is sharded over GPUs (pass 0, n for everything).
+ * X_one_hot == NULL (here and in stage -1 of gm_tower_stage): the attributes are those of the previous call on this
+ * workspace, so mlp_in_X(X) (model/gnn.py:154) is taken from the workspace instead of being recomputed -- the structure
+ * steps of ModelAsync.sample condition on the final attributes (model/diffusion.py:1379-1401), only t and A_t change. */
 int gm_tower_workspace_bytes(const gm_tower_dims* dims, int64_t n, size_t* bytes);
 int gm_tower_forward(const gm_tower_dims* dims, const float* const* params, int64_t n, const float* t_float,
                      const float* X_one_hot, const int32_t* Y, const int32_t* rowptr, const int32_t* colidx,
