@@ -78,6 +78,82 @@ k_spmm_mean(int64_t n, const int32_t* __restrict__ rowptr, const int32_t* __rest
     }
 }
 
+// XCD-sliced variant for a dense operand that does not fit one XCD's 4 MB L2: the columns are cut into slabs of `sc` <= 8
+// float4 chunks whose n rows fit an L2 (<= 2.5 MB), a group of 8 threads owns a row, and workgroup b works on slab (b % 8) + 8 * round.  Workgroups are dealt
+// round-robin to the 8 XCDs, so every gather of a slab is issued from the XCD whose L2 holds that slab after first touch,
+// instead of each XCD streaming the whole of H through its L2 from the Infinity Cache (measured before: 0.89 GB across
+// the L2 boundary for a 58 MB operand).  A wrong guess about the placement costs speed only.  Same arithmetic per column.
+template <int TPR, bool TRANSPOSED = false>
+__global__ void __launch_bounds__(256)
+k_spmm_mean_xcd(int64_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                const float* __restrict__ H, int64_t ldh, int nchunks, int sc, int64_t rowgroups, float* __restrict__ out,
+                int64_t ldo) {
+    constexpr int CH = 1;                          // sc <= TPR: one float4 chunk per thread
+    const int64_t b = blockIdx.x;
+    const int64_t round = b / (8 * rowgroups);
+    const int slab = (int)(round * 8 + (b & 7));
+    const int64_t rg = (b >> 3) % rowgroups;
+    const int r = threadIdx.x / TPR, t = threadIdx.x % TPR;
+    const int64_t i = rg * (256 / TPR) + r;
+    if (i >= n) return;
+    const int c0 = slab * sc;
+    bool on[CH];
+    int cc[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        cc[k] = c0 + t + k * TPR;
+        on[k] = (t + k * TPR < sc) && (cc[k] < nchunks);
+    }
+    const int bgn = rowptr[i], end = rowptr[i + 1];
+    float4 acc[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (end > bgn) {
+        const float inv_row = 1.0f / (float)(end - bgn);
+        int p = bgn;
+        for (; p + 4 <= end; p += 4) {
+            int j[4];
+            float w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) j[q] = colidx[p + q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[q] = TRANSPOSED ? 1.0f / (float)(rowptr[j[q] + 1] - rowptr[j[q]]) : inv_row;
+            float4 v[4][CH];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int k = 0; k < CH; ++k)
+                    v[q][k] = on[k] ? *reinterpret_cast<const float4*>(H + (int64_t)j[q] * ldh + 4 * cc[k])
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    acc[k].x = __builtin_fmaf(v[q][k].x, w[q], acc[k].x);
+                    acc[k].y = __builtin_fmaf(v[q][k].y, w[q], acc[k].y);
+                    acc[k].z = __builtin_fmaf(v[q][k].z, w[q], acc[k].z);
+                    acc[k].w = __builtin_fmaf(v[q][k].w, w[q], acc[k].w);
+                }
+        }
+        for (; p < end; ++p) {
+            const int j = colidx[p];
+            const float inv = TRANSPOSED ? 1.0f / (float)(rowptr[j + 1] - rowptr[j]) : inv_row;
+#pragma unroll
+            for (int k = 0; k < CH; ++k)
+                if (on[k]) {
+                    const float4 v = *reinterpret_cast<const float4*>(H + (int64_t)j * ldh + 4 * cc[k]);
+                    acc[k].x = __builtin_fmaf(v.x, inv, acc[k].x);
+                    acc[k].y = __builtin_fmaf(v.y, inv, acc[k].y);
+                    acc[k].z = __builtin_fmaf(v.z, inv, acc[k].z);
+                    acc[k].w = __builtin_fmaf(v.w, inv, acc[k].w);
+                }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < CH; ++k)
+        if (on[k]) *reinterpret_cast<float4*>(out + i * ldo + 4 * cc[k]) = acc[k];
+}
+
 // scalar fallback for widths / strides that are not 16-byte friendly
 template <bool TRANSPOSED = false>
 __global__ void k_spmm_mean_scalar(int64_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
@@ -196,6 +272,23 @@ static int launch_spmm(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
         GM_LAUNCH_CHECK();
         return GM_OK;
     }
+#ifndef GM_SPMM_NO_XCD   // (exploration builds define it to time the plain kernel)
+    // operand larger than an L2, rows few enough that an 8-chunk (128 B wide) slab of all of them fits one (n <= 20480):
+    // the leading multiple of 64 chunks goes through the XCD-sliced kernel (8 slabs per round of the 8 XCDs, every lane
+    // busy; 6- and 9-chunk slabs measured no better than the plain kernel), the remaining columns through the plain one
+    if (n * d * 4 > (6ll << 20) && n * 128 <= (5ll << 19) && nchunks >= 64) {
+        const int nx = (nchunks / 64) * 64;
+        const int64_t rowgroups = (n + 31) / 32;
+        const int64_t blocks = (int64_t)(nx / 8) * rowgroups;
+        if (blocks < (1ll << 31)) {
+            hipLaunchKernelGGL((k_spmm_mean_xcd<8, TRANSPOSED>), dim3((unsigned)blocks), dim3(256), 0, s, n, rowptr, colidx, H, ldh,
+                               nx, 8, rowgroups, out, ldo);
+            GM_LAUNCH_CHECK();
+            if (nx == nchunks) return GM_OK;
+            return launch_spmm<TRANSPOSED>(n, rowptr, colidx, H + 4 * nx, ldh, d - 4 * nx, out + 4 * nx, ldo, s);
+        }
+    }
+#endif
     const int rows_per_block = 256 / tpr;
     dim3 grid((unsigned)((n + rows_per_block - 1) / rows_per_block)), block(256);
     if (ch == 1) hipLaunchKernelGGL((k_spmm_mean<1, TRANSPOSED>), grid, block, 0, s, n, rowptr, colidx, H, ldh, nchunks, tpr, out, ldo);

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""A/B timing of gm_spmm_mean across library builds at amazon_computer / Cora shapes (exploration tool; GPU box).
+usage: python tools/spmm_ab.py libA.so libB.so ..."""
+import ctypes as C, os, sys, numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from graphmaker_amd import ops
+dev = torch.device("cuda:0")
+libs = [(p, C.CDLL(os.path.join(ROOT, p))) for p in sys.argv[1:]]
+for (n, dens, d, ld) in [(13752, 2.6e-3, 512, 1744), (13752, 2.6e-3, 576, 576), (13752, 2.6e-3, 64, 1744), (2708, 1.44e-3, 576, 576), (100000, 4e-5, 512, 1760)]:
+    bits = ops.prior_E(n, 1.0 - dens, dens, dev, seed=0)
+    adj = ops.adjacency_from_bitmap(bits, n)
+    H = torch.randn(n, ld, device=dev)
+    line = f"n={n} d={d} ld={ld} nnz={adj.nnz}: "
+    ref = None
+    for p, lib in libs:
+        out = torch.zeros(n, d, device=dev)
+        ts = []
+        for rnd in range(6):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = lib.gm_spmm_mean(C.c_int64(n), C.c_void_p(adj.rowptr.data_ptr()), C.c_void_p(adj.colidx.data_ptr()), C.c_void_p(H.data_ptr()),
+                                  C.c_int64(ld), C.c_int64(d), C.c_void_p(out.data_ptr()), C.c_int64(d), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            e1.record(); torch.cuda.synchronize(); assert rc == 0
+            if rnd: ts.append(e0.elapsed_time(e1))
+        ms = float(np.median(ts))
+        line += f" {os.path.basename(p)[3:-3]:>14s} {ms*1e3:8.1f} us |"
+        if ref is None: ref = out.clone()
+        elif not torch.equal(ref, out): line += " [DIFFERS] "
+    print(line)
