@@ -36,6 +36,8 @@ static inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<u
 // small data movers (gm_nodeops.hip) used by the tower driver
 int launch_gather_rows(int64_t n, int w, const int32_t* idx, const float* table, int64_t ldt, float* dst, int64_t ldd, hipStream_t s);
 int launch_broadcast_row(int64_t n, int w, const float* row, float* dst, int64_t ldd, hipStream_t s);
+int launch_spmm_mean_rows(int64_t n, int64_t hn, const int32_t* rowptr, const int32_t* colidx, const float* H, int64_t ldh,
+                          int64_t d, float* out, int64_t ldo, hipStream_t s);
 int launch_copy2d(int64_t n, int w, const float* src, int64_t lds_, float* dst, int64_t ldd, hipStream_t s);
 
 enum : uint32_t { STREAM_Y = 1, STREAM_X = 2, STREAM_E_PRIOR = 3, STREAM_E = 4 };

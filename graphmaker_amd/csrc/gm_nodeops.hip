@@ -257,9 +257,11 @@ int launch_copy2d(int64_t n, int w, const float* src, int64_t lds_, float* dst, 
 
 using namespace gm;
 
+// n output rows (rowptr[0..n]); hn = rows of the dense operand H (>= n when a rank aggregates only its node block)
 template <bool TRANSPOSED>
 static int launch_spmm(int64_t n, const int32_t* rowptr, const int32_t* colidx, const float* H, int64_t ldh, int64_t d,
-                       float* out, int64_t ldo, hipStream_t s) {
+                       float* out, int64_t ldo, hipStream_t s, int64_t hn = 0) {
+    if (hn < n) hn = n;
     const bool vec = (d % 4 == 0) && (ldh % 4 == 0) && (ldo % 4 == 0) && aligned(H, 16) && aligned(out, 16);
     const int nchunks = (int)(d / 4);
     // threads per row: a power of two in [4,64]; CH chunks per thread covers the row
@@ -276,7 +278,8 @@ static int launch_spmm(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
     // operand larger than an L2, rows few enough that an 8-chunk (128 B wide) slab of all of them fits one (n <= 20480):
     // the leading multiple of 64 chunks goes through the XCD-sliced kernel (8 slabs per round of the 8 XCDs, every lane
     // busy; 6- and 9-chunk slabs measured no better than the plain kernel), the remaining columns through the plain one
-    if (n * d * 4 > (6ll << 20) && n * 128 <= (5ll << 19) && nchunks >= 64) {
+    // (and enough output rows to fill the chip with 32-row workgroups per slab: a rank's 1719-row block measured slower)
+    if (hn * d * 4 > (6ll << 20) && hn * 128 <= (5ll << 19) && nchunks >= 64 && n >= 4096) {
         const int nx = (nchunks / 64) * 64;
         const int64_t rowgroups = (n + 31) / 32;
         const int64_t blocks = (int64_t)(nx / 8) * rowgroups;
@@ -285,7 +288,7 @@ static int launch_spmm(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
                                nx, 8, rowgroups, out, ldo);
             GM_LAUNCH_CHECK();
             if (nx == nchunks) return GM_OK;
-            return launch_spmm<TRANSPOSED>(n, rowptr, colidx, H + 4 * nx, ldh, d - 4 * nx, out + 4 * nx, ldo, s);
+            return launch_spmm<TRANSPOSED>(n, rowptr, colidx, H + 4 * nx, ldh, d - 4 * nx, out + 4 * nx, ldo, s, hn);
         }
     }
 #endif
@@ -296,6 +299,13 @@ static int launch_spmm(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
     else hipLaunchKernelGGL((k_spmm_mean<4, TRANSPOSED>), grid, block, 0, s, n, rowptr, colidx, H, ldh, nchunks, tpr, out, ldo);
     GM_LAUNCH_CHECK();
     return GM_OK;
+}
+
+// tower driver: the aggregation of a rank's node block out of all hn rows of H
+int gm::launch_spmm_mean_rows(int64_t n, int64_t hn, const int32_t* rowptr, const int32_t* colidx, const float* H, int64_t ldh,
+                              int64_t d, float* out, int64_t ldo, hipStream_t s) {
+    GM_REQUIRE(n > 0 && d > 0 && rowptr && H && out && ldh >= d && ldo >= d, "bad arguments");
+    return launch_spmm<false>(n, rowptr, colidx, H, ldh, d, out, ldo, s, hn);
 }
 
 extern "C" int gm_spmm_mean(int64_t n, const int32_t* rowptr, const int32_t* colidx, const float* H, int64_t ldh, int64_t d,
