@@ -150,7 +150,7 @@ def secondary_rooflines(wl, model, bits, dev):
     t_gemm = _time_ms(lambda: ops.linear(A, W, b, relu=True), reps=10)
     tf = 2.0 * n * Hc * Hc / (t_gemm * 1e-3) / 1e12
     return [
-        {"kernel": "gm::k_spmm_mean", "bound": "hbm", "achieved": compulsory / (t_spmm * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+        {"kernel": "gm::k_spmm_mean_xcd (+ gm::k_spmm_mean for the last columns)", "bound": "hbm", "achieved": compulsory / (t_spmm * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
          "unit": "GB/s", "frac": compulsory / (t_spmm * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
          "launch_ms": t_spmm, "bytes_per_launch": compulsory, "gather_GBps": gather / (t_spmm * 1e-3) / 1e9,
          "shape": f"N={n} nnz={nnz} d={d}"},
