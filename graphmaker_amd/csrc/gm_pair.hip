@@ -21,9 +21,13 @@
 // next row (both 32-column strips) while the other runs the VALU epilogue of the row it has just finished; the turn
 // passes through a flag in LDS.  (Left to the hardware, the older wave wins every MFMA arbitration, the younger one
 // starves and later runs alone with its epilogues exposed.)  LDS fragments for k-block q+1 are read while the MFMAs
-// of block q run.  Measured anatomy of one 512-MFMA row-unit (ideal 32,768 cycles): 33.9k with operands in
-// registers, +1.9k for the 176 ds_read_b128 that feed it, +~1k hand-over/epilogue interference (profiles/).  W1 (64 KB) stays in LDS for the whole kernel; per tile the 64 h_i rows and 64 h_j rows are staged
-// (64 KB), i.e. 16 B of HBM/L2 traffic per pair against 33,408 FLOP: MFMA-bound (f32 matrix peak 157 TFLOP/s).
+// of block q run.  The alternation runs straight through tile changes: there is no workgroup barrier in the loop.
+// Waves 0-3 finish a tile one row-unit before waves 4-7; in that time they fetch the next queue item and load its h
+// rows into the (now dead) accumulator registers, and write them to LDS as soon as every wave has issued its last
+// fragment read of the old tile -- while waves 4-7 are still in their last epilogue, which reads no h rows.  Measured anatomy of one 512-MFMA row-unit (ideal 32,768 cycles): 33.9k with operands in
+// registers, +1.9k for the 176 ds_read_b128 that feed it, +~1k hand-over/epilogue interference (profiles/).
+// W1 (64 KB) stays in LDS for the whole kernel; per tile the 64 h_i rows and 64 h_j rows are staged (64 KB), i.e.
+// 16 B of HBM/L2 traffic per pair against 33,408 FLOP: MFMA-bound (f32 matrix peak 157 TFLOP/s).
 #include "gm_common.h"
 
 namespace gm {
@@ -58,6 +62,7 @@ struct PairArgs {
     float* logits_dbg;
     float* post_dbg;
     uint32_t* counter;
+    uint32_t* stall;                // set (never cleared) when an LDS hand-shake below timed out: results are then void
     int ntj;
     int64_t ntiles;
     // work items of the shared queue: items [0, nfull) are whole 64x64 tiles; the remaining tiles (fewer than one per
@@ -88,7 +93,6 @@ __device__ __forceinline__ void decode_tile(const PairArgs& a, int64_t t, int64_
     row_end = a.row_end[r];
 }
 
-// store a float4 of 4 consecutive k into the [even k | odd k] row image
 // queue item -> (tile, first unit, one-past-last unit)
 __device__ __forceinline__ void decode_item(const PairArgs& a, int64_t it, int64_t& tile, int& ub, int& ue) {
     if (it < a.nfull) {
@@ -99,6 +103,7 @@ __device__ __forceinline__ void decode_item(const PairArgs& a, int64_t it, int64
     }
 }
 
+// store a float4 of 4 consecutive k into the [even k | odd k] row image
 __device__ __forceinline__ void put_split(float* row, int c4, float4 v) {
     *reinterpret_cast<float2*>(row + 2 * c4) = make_float2(v.x, v.z);
     *reinterpret_cast<float2*>(row + 64 + 2 * c4) = make_float2(v.y, v.w);
@@ -125,6 +130,44 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ h, int64_t 
         const int r = (q >> 5) & (TILE - 1), c4 = q & 31;
         put_split((which ? hJs : hIs) + r * LDR, c4, v[k]);
     }
+}
+
+// The same staging done by waves 0-3 alone (256 threads, 16 float4 each), split so that the global loads can be in
+// flight while the other waves still read the old tile.
+__device__ __forceinline__ void stage_load_half(const float* __restrict__ h, int64_t n, int64_t i0, int64_t j0, int gt,
+                                                float4 (&v)[16]) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int q = gt + k * (PAIR_THREADS / 2);
+        const int which = q >> 11;
+        const int r = (q >> 5) & (TILE - 1), c4 = q & 31;
+        int64_t node = (which ? j0 : i0) + r;
+        node = node < n ? node : n - 1;
+        v[k] = *reinterpret_cast<const float4*>(h + node * HE + 4 * c4);
+    }
+}
+__device__ __forceinline__ void stage_store_half(float* hIs, float* hJs, int gt, const float4 (&v)[16]) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int q = gt + k * (PAIR_THREADS / 2);
+        const int which = q >> 11;
+        const int r = (q >> 5) & (TILE - 1), c4 = q & 31;
+        put_split((which ? hJs : hIs) + r * LDR, c4, v[k]);
+    }
+}
+
+// Wait until the first `cnt` ints at `flags` are all >= need (every lane returns the same answer).  These waits guard
+// LDS contents, so they are long; a wave that gives up reports it through PairArgs::stall instead of hanging the GPU.
+__device__ __forceinline__ bool wait_all_ge(volatile int* flags, int cnt, int need, int lane) {
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+        const int v = lane < cnt ? flags[lane] : 0x7fffffff;
+        if (__all(v >= need)) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // later LDS reads stay below the flag read
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return false;
 }
 
 struct Frag {
@@ -173,14 +216,15 @@ __device__ __forceinline__ float relu_bits(float x) {   // max(x, 0) for non-NaN
 }
 
 __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const PairArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[(HE + 2 * TILE) * LDR + HE + 2 * HE + 16];
+    __shared__ __attribute__((aligned(16))) float lds[(HE + 2 * TILE) * LDR + HE + 2 * HE + 32];
     float* W1s = lds;
     float* hIs = W1s + HE * LDR;
     float* hJs = hIs + TILE * LDR;
     float* b1s = hJs + TILE * LDR;
     float* W2s = b1s + HE;
-    int* tile_s = reinterpret_cast<int*>(W2s + 2 * HE);
-    int* turn_s = tile_s + 4;                      // turn_s[w]: MFMA row-units wave w has issued so far (hand-off flags)
+    int* tile_s = reinterpret_cast<int*>(W2s + 2 * HE);   // tile_s[0..1]: ring of queue items, [2]: items published
+    int* stg_s = tile_s + 4;                       // stg_s[w], w < 4: tiles wave w has staged
+    int* turn_s = tile_s + 8;                      // turn_s[w]: MFMA row-units wave w has issued so far (hand-off flags)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -197,12 +241,22 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
     if (tid < 2 * HE) W2s[tid] = a.W2[tid];
     const float b20 = a.b2[0], b21 = a.b2[1];
 
-    if (tid == 0) *tile_s = (int)atomicAdd(a.counter, 1u);
+    if (tid == 0) { tile_s[0] = (int)atomicAdd(a.counter, 1u); tile_s[2] = 0; }
     if (tid < 8) turn_s[tid] = 0;
+    if (tid < 4) stg_s[tid] = 0;
     __syncthreads();
-    int64_t t = *tile_s;
-    bool staged = false;
+    int64_t t = tile_s[0];
+    int seq = 0;                                   // queue items this workgroup has finished (same in every wave)
     int units_done = 0;                            // row-units this wave has multiplied (same count in every wave)
+    bool stalled = false;
+    if (t < a.nitems) {                            // first item: staged by everybody, behind a barrier
+        int64_t i0, j0, row_end, tile;
+        int tj, ub, ue;
+        decode_item(a, t, tile, ub, ue);
+        decode_tile(a, tile, i0, j0, tj, row_end);
+        stage_tile(a.h, a.n, i0, j0, hIs, hJs, tid);
+    }
+    __syncthreads();
     volatile int* my_turn = turn_s + wv;
     volatile int* partner_turn = turn_s + (wv ^ 4);
 #ifdef GM_PAIR_STAMP   // diagnostic build: cycle sums of wave 0 / wave 4 of block 0 -> post_dbg (never in the product)
@@ -216,10 +270,8 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
         decode_item(a, t, tile, ub, ue);
         decode_tile(a, tile, i0, j0, tj, row_end);
 
-        if (!staged) {   // first tile of this workgroup; later tiles are staged at the hand-over below
-            stage_tile(a.h, a.n, i0, j0, hIs, hJs, tid);
-            __syncthreads();
-        }
+        // the h rows of item number `seq` are in LDS once waves 0-3 have all staged `seq` tiles
+        stalled |= !wait_all_ge(stg_s, 4, seq, lane);
 
         floatx16 acc[2][4];
         // 8 row-units per wave and tile.  The two waves of a SIMD (w, w+4) alternate on the matrix pipe: group 0 runs
@@ -375,20 +427,35 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
             st_phase += STAMP() - ph0;
 #endif
         }
-        // ---- tile hand-over: after this barrier nobody reads the tile's h rows any more; fetch + stage the next tile
-        if (tid == 0) *tile_s = (int)atomicAdd(a.counter, 1u);
-        __syncthreads();
-        t = *tile_s;
-        if (t < a.nitems) {
+        // ---- tile hand-over, no barrier.  Ordering rests on the LDS flags (LDS serves a wave's requests in order):
+        //   * a wave publishes turn_s after the last fragment read of its unit was issued;
+        //   * waves 0-3 overwrite the h rows only after all 8 waves have published the last unit of this item;
+        //   * nobody reads the new rows before all of waves 0-3 have published stg_s (the wait at the loop head).
+        // The epilogue touches no h rows, so waves 4-7 finish theirs under the staging and the next item's first unit.
+        ++seq;
+        if (wv == 0) {
+            if (lane == 0) {
+                tile_s[seq & 1] = (int)atomicAdd(a.counter, 1u);   // slot last read before item seq-1 began
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                *reinterpret_cast<volatile int*>(tile_s + 2) = seq;
+            }
+        }
+        stalled |= !wait_all_ge(tile_s + 2, 1, seq, lane);
+        t = reinterpret_cast<volatile int*>(tile_s)[seq & 1];
+        if (grp == 0 && t < a.nitems) {
             int64_t ni0, nj0, nre, ntile;
             int ntj_, nub, nue;
             decode_item(a, t, ntile, nub, nue);
             decode_tile(a, ntile, ni0, nj0, ntj_, nre);
-            stage_tile(a.h, a.n, ni0, nj0, hIs, hJs, tid);
+            float4 v[16];
+            stage_load_half(a.h, a.n, ni0, nj0, tid, v);
+            stalled |= !wait_all_ge(turn_s, 8, units_done, lane);
+            stage_store_half(hIs, hJs, tid, v);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) *reinterpret_cast<volatile int*>(stg_s + wv) = seq;
         }
-        staged = true;
-        __syncthreads();
     }
+    if (stalled && lane == 0) atomicOr(a.stall, 1u);
 #ifdef GM_PAIR_STAMP
     if (blockIdx.x == 0 && lane == 0 && (wv == 0 || wv == 4) && a.post_dbg) {
         float* o = a.post_dbg + 8 * grp;
@@ -419,6 +486,7 @@ extern "C" int gm_pair_score_sample_ranges(int64_t n, int64_t hE, const float* h
     a.u = u; a.seed = seed; a.step = step;
     a.out_upper = out_upper; a.logits_dbg = logits_dbg; a.post_dbg = post_dbg;
     a.counter = static_cast<uint32_t*>(workspace);
+    a.stall = a.counter + 16;
     a.ntj = (int)((n + TILE - 1) / TILE);
     a.nranges = 0;
     a.tile_base[0] = 0;

@@ -272,7 +272,7 @@ class BaseModel(nn.Module):
             with self.phase("allgather_h"):
                 h = parallel.all_gather_node_rows(plan, h_pad, group)[:n]
         if self._pair_ws is None or self._pair_ws.device != h.device:
-            self._pair_ws = torch.empty(256, dtype=torch.uint8, device=h.device)
+            self._pair_ws = ops.pair_workspace(h.device)
         W1, b1, W2, b2 = pred_E.pair_params()
         ranges = [(0, n)] if plan is None else plan.pair_chunks()
         upper = torch.zeros((n if plan is None else plan.padded_pair_rows, bits_t.shape[1]), dtype=torch.int32,
@@ -323,6 +323,8 @@ class BaseModel(nn.Module):
         n, Fa = self.num_nodes, self.num_attrs_X
         if self.__dict__.get("_csr_workspace") is not None:
             self._csr_workspace.check()                                     # the one host read of a trajectory
+        if self._pair_ws is not None:
+            ops.check_pair_workspace(self._pair_ws)
         X = torch.transpose(x_onehot.reshape(n, Fa, -1), 0, 1)             # model/diffusion.py:899-901
         Y_one_hot = F.one_hot(Y32.long(), num_classes=self.num_classes_Y).float()
         if dense:
@@ -451,7 +453,7 @@ class ModelSync(BaseModel):
             h_on_wire.wait()
         h = h_pad[:n]
         if self._pair_ws is None or self._pair_ws.device != dev:
-            self._pair_ws = torch.empty(256, dtype=torch.uint8, device=dev)
+            self._pair_ws = ops.pair_workspace(dev)
         W1, b1, W2, b2 = ge.pred_E.pair_params()
         upper = torch.zeros((plan.padded_pair_rows, bits_t.shape[1]), dtype=torch.int32, device=dev)
         with self.phase("pair"):

@@ -193,6 +193,18 @@ def hadamard_gather(h, src, dst):
 
 
 # ------------------------------------------------------------------ structure denoiser
+def pair_workspace(device):
+    """Workspace of gm_pair_score_sample*: tile counter + the sticky trouble flag (include/graphmaker_hip.h)."""
+    return torch.zeros(256, dtype=torch.uint8, device=device)
+
+
+def check_pair_workspace(workspace):
+    """Host read (synchronises): raise if a pair kernel that used this workspace reported a timed-out hand-shake."""
+    if int(workspace[64:68].view(torch.int32).item()) != 0:
+        raise RuntimeError("gm_pair_score_sample: a wave timed out waiting for an LDS hand-shake; the sampled "
+                           "adjacency of this trajectory is void (see include/graphmaker_hip.h)")
+
+
 def pair_score_sample(h, W1, b1, W2, b2, bits_t, tab, *, seed=0, step=0, u=None, row_begin=0, row_end=None,
                       row_ranges=None, out_upper=None, workspace=None, want_debug=False):
     """All pairs i<j of rows [row_begin,row_end) -- or of up to four ascending, disjoint `row_ranges` [(b0,e0),...] in
@@ -205,8 +217,9 @@ def pair_score_sample(h, W1, b1, W2, b2, bits_t, tab, *, seed=0, step=0, u=None,
     dev = h.device
     if out_upper is None:
         out_upper = torch.zeros((n, wpr), dtype=torch.int32, device=dev)
-    if workspace is None:
-        workspace = torch.empty(256, dtype=torch.uint8, device=dev)
+    own_workspace = workspace is None
+    if own_workspace:
+        workspace = pair_workspace(dev)
     P = n * (n - 1) // 2
     lg = torch.zeros((P, 2), dtype=torch.float32, device=dev) if want_debug else None
     po = torch.zeros((P, 2), dtype=torch.float32, device=dev) if want_debug else None
@@ -222,6 +235,8 @@ def pair_score_sample(h, W1, b1, W2, b2, bits_t, tab, *, seed=0, step=0, u=None,
     L.call("gm_pair_score_sample_ranges", I64(n), I64(hE), ptr(h), ptr(W1), ptr(b1), ptr(W2), ptr(b2), ptr(bits_t),
            I64(wpr), tab_host, I32(len(flat) // 2), ranges_host, ptr(u), U64(seed), U32(step), ptr(out_upper), ptr(lg),
            ptr(po), ptr(workspace), stream_ptr())
+    if own_workspace:
+        check_pair_workspace(workspace)
     return (out_upper, lg, po) if want_debug else out_upper
 
 

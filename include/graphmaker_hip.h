@@ -132,7 +132,12 @@ int gm_hadamard_gather(int64_t B, int64_t d, const int64_t* src, const int64_t* 
  * `tab`) -> draw (:421).  Nothing P-sized is stored: the result is the upper-triangle bitmap `out_upper`
  * (rows [row_begin,row_end), words w >= (row>>5) are written).
  * hE must be 128.  tab: HOST pointer to 8 floats tab[(i*2+k)*2+e] = Q_t[k][e]*Qbar_s[i][k]/Qbar_t[i][e].
- * workspace: >= 256 bytes (tile counter).  logits_dbg/post_dbg: optional (P,2) arrays indexed by rank. */
+ * workspace: >= 256 bytes, zeroed by the caller when it is allocated.  Word 0 is the tile counter (cleared by every
+ * call).  Word 16 is a sticky trouble flag: the kernel's waves hand tiles to each other through flags in LDS without
+ * workgroup barriers, and a wave that waits for such a flag far beyond any legitimate delay sets the word and carries
+ * on, so that the GPU is never hung; the outputs of that call are then void.  The library never clears it: test it
+ * wherever the caller synchronises anyway (graphmaker_amd does so once per trajectory).
+ * logits_dbg/post_dbg: optional (P,2) arrays indexed by rank. */
 int gm_pair_score_sample(int64_t n, int64_t hE, const float* h, const float* W1, const float* b1, const float* W2,
                          const float* b2, const uint32_t* bits_t, int64_t wpr, const float* tab,
                          int64_t row_begin, int64_t row_end, const float* u, uint64_t seed, uint32_t step,

@@ -31,4 +31,4 @@ for rnd in range(4):
         if rnd: res[p].append(e0.elapsed_time(e1))
         sums[p] = int(out.to(torch.int64).abs().sum().item())
 for p, _ in libs:
-    ms = np.median(res[p]); print(f"{p:60s} {ms:8.3f} ms  {33408*P/ms/1e9:7.1f} TF  min {min(res[p]):.3f}  checksum {sums[p]}")
+    ms = np.median(res[p]); print(f"{p:60s} {ms:8.3f} ms  {33408*P/ms/1e9:7.1f} TF  min {min(res[p]):.3f}  checksum {sums[p]}  stall {int(ws[64:68].view(torch.int32).item())}")
