@@ -262,6 +262,7 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
 #ifdef GM_PAIR_STAMP   // diagnostic build: cycle sums of wave 0 / wave 4 of block 0 -> post_dbg (never in the product)
     unsigned long long st_mma = 0, st_epi = 0, st_phase = 0, st_n = 0, st_init = 0;
 #define STAMP() __builtin_readcyclecounter()
+    const unsigned long long st_c0 = STAMP(), st_r0 = wall_clock64();   // shader cycles vs the constant 100 MHz clock
 #endif
 
     while (t < a.nitems) {
@@ -460,6 +461,7 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
     if (blockIdx.x == 0 && lane == 0 && (wv == 0 || wv == 4) && a.post_dbg) {
         float* o = a.post_dbg + 8 * grp;
         o[0] = (float)st_mma; o[1] = (float)st_epi; o[2] = (float)st_phase; o[3] = (float)st_n; o[4] = (float)st_init;
+        o[5] = (float)(STAMP() - st_c0); o[6] = (float)(wall_clock64() - st_r0);
     }
 #endif
 }
