@@ -221,6 +221,10 @@ static int launch_linear(int64_t M, int64_t N, int64_t K, const float* A, int64_
 #define GM_GEMM_BIG_TILES 400   // at least this many 128x128 tiles: the 128x128 / 8-wave configuration
 #endif
 
+#ifndef GM_GEMM_SMALL_TILES
+#define GM_GEMM_SMALL_TILES 384   // at most this many 64x64 tiles: the 32x64 configuration
+#endif
+
 extern "C" int gm_linear(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw,
                          const float* bias, float* C, int64_t ldc, int relu, gm_stream_t stream) {
     GM_REQUIRE(M > 0 && N > 0 && K > 0 && A && W && C, "bad arguments");
@@ -233,5 +237,9 @@ extern "C" int gm_linear(int64_t M, int64_t N, int64_t K, const float* A, int64_
     // wide layers with many rows: 128x128 block tile, 4x2 waves of 32x64 (half the operand traffic per FLOP);
     // everything else: 64x64 block tile, 2x2 waves of 32x32, four workgroups per CU
     if (tiles128 >= GM_GEMM_BIG_TILES) return launch_linear<2, 4, 32, 2, 4, 2>(M, N, K, A, lda, W, ldw, bias, C, ldc, relu, s);
+    // few 64x64 tiles (a rank's row block, Cora-sized graphs, the 128- and 64-wide layers): the serial K walk of one
+    // workgroup is the whole run time, so halve the rows per wave and double the workgroups (32x64 block tile)
+    const int64_t tiles64 = ((N + 63) / 64) * ((M + 63) / 64);
+    if (tiles64 <= GM_GEMM_SMALL_TILES || N <= 128) return launch_linear<1, 2, 32, 5>(M, N, K, A, lda, W, ldw, bias, C, ldc, relu, s);
     return launch_linear<2, 2, 32, 4>(M, N, K, A, lda, W, ldw, bias, C, ldc, relu, s);
 }
