@@ -100,44 +100,41 @@ __global__ void k_row_degree(int64_t n, int64_t wpr, const uint32_t* __restrict_
     if (lane == 0) deg[i] = cnt;
 }
 
-// exclusive scan of deg[0..n) into rowptr[0..n] (in place: deg == rowptr allowed), single block of 1024 threads
-__global__ void k_exclusive_scan(int64_t n, int32_t* __restrict__ rowptr) {
+// exclusive scan of deg[0..n) into rowptr[0..n], in place, single block of 1024 threads: every thread sums a
+// contiguous run of ceil(n/1024) entries, the 1024 sums are scanned once, and the run is rewritten (2 barriers in all).
+// capacity >= 0: every entry is clamped to it and *overflow |= (total > capacity).  With a caller-owned colidx buffer of
+// fixed capacity no host read of the edge count is needed: every consumer of (rowptr, colidx) stays inside the buffer,
+// and the flag tells the host later that a result built on the truncated list must be discarded.
+__global__ void __launch_bounds__(1024) k_exclusive_scan(int64_t n, int32_t* __restrict__ rowptr, int64_t capacity,
+                                                         int32_t* __restrict__ overflow) {
     __shared__ int32_t wsum[16];
-    __shared__ int32_t carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (int64_t base = 0; base < n; base += 1024) {
-        const int64_t idx = base + tid;
-        int32_t v = idx < n ? rowptr[idx] : 0;
-        int32_t inc = v;
-        for (int off = 1; off < 64; off <<= 1) {
-            int32_t t = __shfl_up(inc, off);
-            if (lane >= off) inc += t;
-        }
-        if (lane == 63) wsum[wv] = inc;
-        __syncthreads();
-        int32_t woff = 0;
-        for (int k = 0; k < wv; ++k) woff += wsum[k];
-        const int32_t carry = carry_s;
-        if (idx < n) rowptr[idx] = carry + woff + inc - v;
-        __syncthreads();
-        if (tid == 1023) carry_s = carry + woff + inc;
-        __syncthreads();
+    const int64_t c = (n + 1023) / 1024;
+    const int64_t b = tid * c < n ? tid * c : n, e = b + c < n ? b + c : n;
+    int32_t sum = 0;
+    for (int64_t i = b; i < e; ++i) sum += rowptr[i];
+    int32_t inc = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int32_t t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
     }
-    if (tid == 0) rowptr[n] = carry_s;
-}
-
-// rowptr[0..n] = min(rowptr, capacity); *overflow |= (rowptr[n] > capacity).  With a caller-owned colidx buffer of fixed
-// capacity no host read of the edge count is needed: every consumer of (rowptr, colidx) stays inside the buffer, and
-// the flag tells the host later that a result built on the truncated list must be discarded.
-__global__ void k_clamp_rowptr(int64_t n, int64_t capacity, int32_t* __restrict__ rowptr, int32_t* __restrict__ overflow) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx > n) return;
-    const int64_t v = rowptr[idx];
-    if (v > capacity) {
-        rowptr[idx] = (int32_t)capacity;
-        if (idx == n) atomicOr(overflow, 1);
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int32_t woff = 0, total = 0;
+    for (int k = 0; k < 16; ++k) {
+        if (k < wv) woff += wsum[k];
+        total += wsum[k];
+    }
+    const int32_t cap = capacity >= 0 ? (int32_t)capacity : 0x7fffffff;
+    int32_t run = woff + inc - sum;
+    for (int64_t i = b; i < e; ++i) {
+        const int32_t v = rowptr[i];
+        rowptr[i] = run < cap ? run : cap;
+        run += v;
+    }
+    if (tid == 0) {
+        rowptr[n] = total < cap ? total : cap;
+        if (total > cap) atomicOr(overflow, 1);
     }
 }
 
@@ -229,7 +226,7 @@ extern "C" int gm_csr_rowptr(int64_t n, int64_t wpr, const uint32_t* bits, int u
     GM_REQUIRE(bits && rowptr, "null pointer");
     hipLaunchKernelGGL(k_row_degree, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, as_stream(stream), n, wpr, bits, upper_only, rowptr);
     GM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, as_stream(stream), n, rowptr);
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, as_stream(stream), n, rowptr, (int64_t)-1, (int32_t*)nullptr);
     GM_LAUNCH_CHECK();
     return GM_OK;
 }
@@ -237,9 +234,11 @@ extern "C" int gm_csr_rowptr(int64_t n, int64_t wpr, const uint32_t* bits, int u
 extern "C" int gm_csr_rowptr_capped(int64_t n, int64_t wpr, const uint32_t* bits, int upper_only, int64_t capacity,
                                     int32_t* rowptr, int32_t* overflow, gm_stream_t stream) {
     GM_REQUIRE(capacity > 0 && capacity < (1ll << 31) && overflow, "bad capacity or null overflow flag");
-    if (int rc = gm_csr_rowptr(n, wpr, bits, upper_only, rowptr, stream)) return rc;
-    hipLaunchKernelGGL(k_clamp_rowptr, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, as_stream(stream), n, capacity, rowptr,
-                       overflow);
+    if (int rc = check_bitmap_args(n, wpr)) return rc;
+    GM_REQUIRE(bits && rowptr, "null pointer");
+    hipLaunchKernelGGL(k_row_degree, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, as_stream(stream), n, wpr, bits, upper_only, rowptr);
+    GM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, as_stream(stream), n, rowptr, capacity, overflow);
     GM_LAUNCH_CHECK();
     return GM_OK;
 }
