@@ -146,3 +146,16 @@ def test_shard_plan_covers_every_pair_once_and_balances(n, world):
         b, e = p.node_range()
         rows[b:e] += 1
     assert (rows == 1).all()
+
+
+def test_pair_workspace_trouble_flag_is_reported():
+    """include/graphmaker_hip.h, gm_pair_score_sample: word 16 of the workspace is the sticky trouble flag the host tests."""
+    from graphmaker_amd import ops
+    ws = ops.pair_workspace(torch.device("cpu"))
+    assert ws.numel() >= 256 and int(ws.sum()) == 0
+    ops.check_pair_workspace(ws)                       # clean workspace: nothing to report
+    ws[0:4].view(torch.int32)[0] = 12345               # the tile counter is not a trouble sign
+    ops.check_pair_workspace(ws)
+    ws[64:68].view(torch.int32)[0] = 1
+    with pytest.raises(RuntimeError, match="hand-shake"):
+        ops.check_pair_workspace(ws)
