@@ -45,11 +45,13 @@ k_symmetrize(int64_t n, int64_t wpr, const uint32_t* __restrict__ upper, uint32_
     const int64_t i = I * 32 + li;
     const int wavesPerBlock = blockDim.x >> 6;
     const int wv = threadIdx.x >> 6;
-    // blockIdx.y interleaves the word range over gridDim.y blocks (a row tile alone is too little latency-bound work per CU)
+    // blockIdx.y cuts the word range into gridDim.y contiguous pieces (a row tile alone is too little latency-bound work
+    // per CU); a block walks its piece 8 words = 32 bytes of every row at a time, so the four visits to a 128-byte line
+    // come from one CU back to back instead of from four workgroups on different XCDs
     const int64_t per_it = 2 * wavesPerBlock * (int64_t)gridDim.y;
     const int64_t wsteps = (wpr + per_it - 1) / per_it;
     for (int64_t it = 0; it < wsteps; ++it) {            // uniform trip count: the ballots need every lane
-        const int64_t w = (it * gridDim.y + blockIdx.y) * 2 * wavesPerBlock + wv * 2 + half;
+        const int64_t w = (blockIdx.y * wsteps + it) * 2 * wavesPerBlock + wv * 2 + half;
         const bool inw = w < wpr;
         uint32_t own = 0, src = 0;
         if (inw && i < n && w >= I && w * 32 < n) {

@@ -12,9 +12,10 @@ __global__ void k_attr_posterior_sample(int64_t n, int64_t F, const float* __res
                                         const float* __restrict__ u, uint64_t seed, uint32_t step, int64_t v_begin,
                                         int64_t v_end, uint8_t* __restrict__ x_s, float* __restrict__ onehot,
                                         float* __restrict__ post) {
-    const int64_t g = v_begin * F + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= v_end * F) return;
-    const int64_t v = g / F, f = g % F;
+    // grid: x = node row, y = 256-attribute chunk (no 64-bit division per element)
+    const int64_t v = v_begin + blockIdx.x, f = (int64_t)blockIdx.y * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const int64_t g = v * F + f;
     const float2 l = *reinterpret_cast<const float2*>(logits + 2 * g);
     float q0, q1, p0, p1;
     softmax2(l.x, l.y, q0, q1);
@@ -58,9 +59,9 @@ __global__ void k_prior_Y(int64_t n, int C, const float* __restrict__ Ym, const 
 
 __global__ void k_prior_X(int64_t n, int64_t F, const float* __restrict__ Xm, const float* __restrict__ u, uint64_t seed,
                           uint8_t* __restrict__ x, float* __restrict__ onehot) {
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n * F) return;
-    const int64_t v = g / F, f = g % F;
+    const int64_t v = blockIdx.x, f = (int64_t)blockIdx.y * blockDim.x + threadIdx.x;   // x = node row, y = attribute chunk
+    if (f >= F) return;
+    const int64_t g = v * F + f;
     const int64_t idx = f * n + v;
     const float uu = u ? u[idx] : u_idx64(seed, 0u, STREAM_X, (uint64_t)idx);
     const bool b = draw2(uu, Xm[2 * f], Xm[2 * f + 1]);
@@ -103,7 +104,8 @@ extern "C" int gm_attr_posterior_sample(int64_t n, int64_t F, const float* logit
     GM_REQUIRE(n * F < (1ll << 39), "n*F too large");
     GM_REQUIRE(aligned(logits, 8) && (!onehot_out || aligned(onehot_out, 8)) && (!post_dbg || aligned(post_dbg, 8)),
                "logits/onehot/post must be 8-byte aligned");
-    hipLaunchKernelGGL(k_attr_posterior_sample, dim3(blocks_for((v_end - v_begin) * F)), dim3(256), 0, as_stream(stream), n, F,
+    GM_REQUIRE(v_end - v_begin < (1ll << 31) && (F + 255) / 256 <= 65535, "grid too large");
+    hipLaunchKernelGGL(k_attr_posterior_sample, dim3((unsigned)(v_end - v_begin), (unsigned)((F + 255) / 256)), dim3(256), 0, as_stream(stream), n, F,
                        logits, x_t, tab, u, seed, step, v_begin, v_end, x_s, onehot_out, post_dbg);
     GM_LAUNCH_CHECK();
     return GM_OK;
@@ -135,7 +137,8 @@ extern "C" int gm_prior_X(int64_t n, int64_t F, const float* X_marginal, const f
                           float* onehot_out, gm_stream_t stream) {
     GM_REQUIRE(n > 0 && F > 0 && X_marginal && x, "bad arguments");
     GM_REQUIRE(!onehot_out || aligned(onehot_out, 8), "onehot must be 8-byte aligned");
-    hipLaunchKernelGGL(k_prior_X, dim3(blocks_for(n * F)), dim3(256), 0, as_stream(stream), n, F, X_marginal, u, seed, x,
+    GM_REQUIRE(n < (1ll << 31) && (F + 255) / 256 <= 65535, "grid too large");
+    hipLaunchKernelGGL(k_prior_X, dim3((unsigned)n, (unsigned)((F + 255) / 256)), dim3(256), 0, as_stream(stream), n, F, X_marginal, u, seed, x,
                        onehot_out);
     GM_LAUNCH_CHECK();
     return GM_OK;
