@@ -9,7 +9,6 @@ A one-rank RCCL group covers the NCCL stream hand-over of the same path.
 import os
 import socket
 
-import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
