@@ -153,6 +153,9 @@ def secondary_rooflines(wl, model, bits, dev):
         {"kernel": "gm::k_spmm_mean_xcd (+ gm::k_spmm_mean for the last columns)", "bound": "hbm", "achieved": compulsory / (t_spmm * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
          "unit": "GB/s", "frac": compulsory / (t_spmm * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
          "launch_ms": t_spmm, "bytes_per_launch": compulsory, "gather_GBps": gather / (t_spmm * 1e-3) / 1e9,
+         # what actually bounds it: rows gathered out of an XCD's L2, measured ceiling 16.8-18.8 TB/s chip-wide
+         # (MI355X_MICROARCH.md, "Indexed rows: gather into LDS")
+         "gather_frac_of_l2_gather_ceiling": gather / (t_spmm * 1e-3) / 1e9 / 16800.0,
          "shape": f"N={n} nnz={nnz} d={d}"},
         {"kernel": "gm::k_linear", "bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
          "frac": tf / F32_MFMA_PEAK_TFLOPS, "traffic": None, "launch_ms": t_gemm, "shape": f"M={n} N={Hc} K={Hc} +bias+ReLU"},
