@@ -104,6 +104,47 @@ class _Linear(torch.autograd.Function):
         return dx, dW, db, None
 
 
+class _Mlp2(torch.autograd.Function):
+    """Linear -> ReLU -> Linear [-> ReLU] (mlp_in_X, mlp_out and the pair MLP, model/gnn.py:116-126,138-142,227-231) as one
+    tape node, so that the backward applies the inner ReLU mask in the epilogue of the GEMM that produces the hidden
+    gradient instead of in a pass of its own (the pair MLP's hidden gradient is batch x 128 floats: 1 GB per step)."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, relu_out):
+        x, W1, W2 = _c(x), _c(W1), _c(W2)
+        require(x, torch.float32, "x")
+        M, K = x.shape
+        H, N = W1.shape[0], W2.shape[0]
+        if W1.shape[1] != K or W2.shape[1] != H:
+            raise ValueError(f"mlp2: x is {tuple(x.shape)}, W1 is {tuple(W1.shape)}, W2 is {tuple(W2.shape)}")
+        y1 = torch.empty((M, H), dtype=torch.float32, device=x.device)
+        L.call("gm_linear", I64(M), I64(H), I64(K), ptr(x), I64(K), ptr(W1), I64(K), ptr(b1), ptr(y1), I64(H), I32(1), stream_ptr())
+        y2 = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        L.call("gm_linear", I64(M), I64(N), I64(H), ptr(y1), I64(H), ptr(W2), I64(H), ptr(b2), ptr(y2), I64(N), I32(int(relu_out)),
+               stream_ptr())
+        ctx.relu_out = relu_out
+        ctx.has_bias = (b1 is not None, b2 is not None)
+        ctx.save_for_backward(x, W1, W2, y1, y2 if relu_out else None)
+        return y2
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W1, W2, y1, y2 = ctx.saved_tensors
+        g = _c(g)
+        if ctx.relu_out:
+            gm = torch.empty_like(g)
+            L.call("gm_relu_bwd", I64(g.numel()), ptr(g), ptr(y2), ptr(gm), stream_ptr())
+            g = gm
+        M, K = x.shape
+        H, N = W1.shape[0], W2.shape[0]
+        need = ctx.needs_input_grad
+        dW2 = gemm(True, True, N, H, M, g, N, y1, H) if need[3] else None
+        db2 = colsum(g) if ctx.has_bias[1] and need[4] else None
+        g1 = gemm(False, True, M, H, N, g, N, W2, H, mask=y1)          # (dY W2) where the hidden unit was active
+        dx, dW1, db1 = _linear_backward(x, W1, g1, (need[0], need[1], ctx.has_bias[0] and need[2]))
+        return dx, dW1, db1, dW2, db2, None
+
+
 class _UpdateBlock(torch.autograd.Function):
     """Linear -> ReLU -> LayerNorm of GNNLayer / MLPLayer (model/gnn.py:27-38)."""
 
@@ -264,6 +305,10 @@ class _Dropout(torch.autograd.Function):
 
 def linear(x, W, b=None, relu=False):
     return _Linear.apply(x, W, b, relu)
+
+
+def mlp2(x, W1, b1, W2, b2, relu_out=False):
+    return _Mlp2.apply(x, W1, b1, W2, b2, relu_out)
 
 
 def update_block(x, W, b, gamma, beta, eps=1e-5):

@@ -97,7 +97,10 @@ class _TowerBase(nn.Module):
         Y32 = (Y_real if Y_real.dtype == torch.int32 else Y_real.to(torch.int32)).contiguous()
         t = t_float.reshape(1, 1).to(torch.float32)
         h_t = lin(self.mlp_in_t[2], lin(self.mlp_in_t[0], t, True), True)                     # (1, hidden_t)
-        h_X = lin(self.mlp_in_X[2], lin(self.mlp_in_X[0], X_t_one_hot, True), True)
+        def mlp2(seq, x, relu_out):
+            return ag.mlp2(x, seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias, relu_out)
+
+        h_X = mlp2(self.mlp_in_X, X_t_one_hot, True)
         h_Y = ag.embedding(self.emb_Y.weight, Y32)
         h_t_exp = h_t.expand(n, -1)
         hX_list, hY_list = [h_X], [h_Y]
@@ -119,7 +122,7 @@ class _TowerBase(nn.Module):
             hX_list.append(h_X)
             hY_list.append(h_Y)
         h_cat = torch.cat(hX_list + hY_list + [h_t_exp], dim=1)
-        return lin(self.mlp_out[2], lin(self.mlp_out[0], h_cat, True), False)
+        return mlp2(self.mlp_out, h_cat, False)
 
     def _run(self, t_float, X_t_one_hot, Y_real, A_t, want_hcat=False, rows=None, out=None, reuse_X=False):
         """reuse_X: the caller guarantees that X_t_one_hot, the parameters and the node count are those of the previous
@@ -243,7 +246,7 @@ class LinkPredictor(nn.Module):
         W1, b1, W2, b2 = self.pair_params()
         if torch.is_grad_enabled() and (h.requires_grad or W1.requires_grad):
             z = ag.hadamard_gather(h, src, dst)
-            return ag.linear(ag.linear(z, W1, b1, True), W2, b2, False)
+            return ag.mlp2(z, W1, b1, W2, b2, False)
         z = ops.hadamard_gather(h, src.contiguous(), dst.contiguous())     # model/gnn.py:246
         return ops.linear(ops.linear(z, W1, b1, relu=True), W2, b2)        # model/gnn.py:248
 
