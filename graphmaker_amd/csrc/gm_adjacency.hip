@@ -76,6 +76,83 @@ k_symmetrize(int64_t n, int64_t wpr, const uint32_t* __restrict__ upper, uint32_
     }
 }
 
+// Large graphs: one block per 512x512-bit tile (RB, CB >= RB) of the upper triangle, staged through LDS so that both the
+// tile and its transpose leave as 64-byte row segments (the kernel above reads and writes 8 bytes per row and wave).
+// The 32x32 sub-tiles are transposed across the lanes of a half-wave by the 5-stage butterfly (exchange with lane^s the
+// half-blocks of s bits, s = 16..1): lane c ends up with column c.
+constexpr int SYM_T = 512, SYM_W = SYM_T / 32, SYM_LD = SYM_W + 1;
+
+__device__ __forceinline__ uint32_t transpose32_across_lanes(uint32_t x, int li) {
+    const uint32_t masks[5] = {0x0000FFFFu, 0x00FF00FFu, 0x0F0F0F0Fu, 0x33333333u, 0x55555555u};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int sft = 16 >> k;
+        const uint32_t m = masks[k];
+        const uint32_t y = (uint32_t)__shfl_xor((int)x, sft);
+        x = (li & sft) ? (((y >> sft) & m) | (x & ~m)) : ((x & m) | ((y & m) << sft));
+    }
+    return x;
+}
+
+__global__ void __launch_bounds__(256)
+k_symmetrize_tiled(int64_t n, int64_t wpr, int nT, const uint32_t* __restrict__ upper, uint32_t* __restrict__ sym) {
+    __shared__ uint32_t Us[SYM_T * SYM_LD];
+    __shared__ uint32_t Ts[SYM_T * SYM_LD];
+    const int tid = threadIdx.x;
+    // block -> (RB, CB): row RB owns nT - RB tiles
+    const int64_t t = blockIdx.x;
+    int lo = 0, hi = nT - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int64_t)mid * nT - (int64_t)mid * (mid - 1) / 2 <= t) lo = mid; else hi = mid - 1;
+    }
+    const int RB = lo, CB = lo + (int)(t - ((int64_t)lo * nT - (int64_t)lo * (lo - 1) / 2));
+    const bool diag = RB == CB;
+#pragma unroll
+    for (int k = 0; k < SYM_T * SYM_W / 4 / 256; ++k) {
+        const int q = tid + 256 * k, r = q >> 2, c4 = q & 3;
+        const int64_t gi = (int64_t)RB * SYM_T + r, w0 = (int64_t)CB * SYM_W + 4 * c4;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        const bool in = gi < n && w0 < wpr;
+        if (in) v = *reinterpret_cast<const uint4*>(upper + gi * wpr + w0);
+        uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (diag) {                                   // keep j >= i
+                const int lw = 4 * c4 + e, rI = r >> 5;
+                if (lw < rI) wd[e] = 0u;
+                else if (lw == rI) wd[e] &= ~((1u << (r & 31)) - 1u);
+            }
+            const int64_t rem = n - (w0 + e) * 32;        // clear padding columns
+            if (rem <= 0) wd[e] = 0u;
+            else if (rem < 32) wd[e] &= (1u << rem) - 1u;
+            Us[r * SYM_LD + 4 * c4 + e] = wd[e];
+        }
+        if (!diag && in) *reinterpret_cast<uint4*>(sym + gi * wpr + w0) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+    }
+    __syncthreads();
+    const int hw = tid >> 5, li = tid & 31;
+    for (int it = 0; it < SYM_W * SYM_W / 8; ++it) {
+        const int st = it * 8 + hw, a = st / SYM_W, b = st % SYM_W;       // rows 32a.. of word b -> rows 32b.. of word a
+        const uint32_t x = transpose32_across_lanes(Us[(32 * a + li) * SYM_LD + b], li);
+        Ts[(32 * b + li) * SYM_LD + a] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SYM_T * SYM_W / 4 / 256; ++k) {
+        const int q = tid + 256 * k, j = q >> 2, c4 = q & 3;
+        const int64_t gj = (int64_t)CB * SYM_T + j, w0 = (int64_t)RB * SYM_W + 4 * c4;
+        if (gj >= n || w0 >= wpr) continue;
+        uint32_t wd[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            wd[e] = Ts[j * SYM_LD + 4 * c4 + e];
+            if (diag) wd[e] |= Us[j * SYM_LD + 4 * c4 + e];
+        }
+        *reinterpret_cast<uint4*>(sym + gj * wpr + w0) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+    }
+}
+
 // ---------------------------------------------------------------- CSR
 __device__ __forceinline__ uint32_t masked_word(const uint32_t* bits, int64_t wpr, int64_t i, int64_t w, int upper_only) {
     uint32_t word = bits[i * wpr + w];
@@ -214,6 +291,14 @@ extern "C" int gm_dense_i64_from_bitmap(int64_t n, int64_t wpr, const uint32_t* 
 extern "C" int gm_symmetrize_upper(int64_t n, int64_t wpr, const uint32_t* upper, uint32_t* sym, gm_stream_t stream) {
     if (int rc = check_bitmap_args(n, wpr)) return rc;
     GM_REQUIRE(upper && sym && upper != sym, "null or aliased pointer");
+    const int64_t nT = (n + SYM_T - 1) / SYM_T;
+    // >= 136 tiles, and a row no wider than the tiles cover: the LDS-staged kernel
+    if (nT >= 16 && nT < 40000 && wpr <= nT * SYM_W && aligned(upper, 16) && aligned(sym, 16)) {
+        hipLaunchKernelGGL(k_symmetrize_tiled, dim3((unsigned)(nT * (nT + 1) / 2)), dim3(256), 0, as_stream(stream), n, wpr,
+                           (int)nT, upper, sym);
+        GM_LAUNCH_CHECK();
+        return GM_OK;
+    }
     const int64_t tiles = (n + 31) / 32;
     int64_t split = (4096 + tiles - 1) / tiles;          // ~4096 workgroups
     if (split > (wpr + 7) / 8) split = (wpr + 7) / 8;
