@@ -191,7 +191,13 @@ __global__ void __launch_bounds__(1024) k_exclusive_scan(int64_t n, int32_t* __r
     const int64_t c = (n + 1023) / 1024;
     const int64_t b = tid * c < n ? tid * c : n, e = b + c < n ? b + c : n;
     int32_t sum = 0;
-    for (int64_t i = b; i < e; ++i) sum += rowptr[i];
+    for (int64_t i = b; i < e; i += 8) {               // 8 independent loads in flight, not one dependent load per entry
+        int32_t v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = i + q < e ? rowptr[i + q] : 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sum += v[q];
+    }
     int32_t inc = sum;
     for (int off = 1; off < 64; off <<= 1) {
         const int32_t t = __shfl_up(inc, off);
@@ -206,10 +212,15 @@ __global__ void __launch_bounds__(1024) k_exclusive_scan(int64_t n, int32_t* __r
     }
     const int32_t cap = capacity >= 0 ? (int32_t)capacity : 0x7fffffff;
     int32_t run = woff + inc - sum;
-    for (int64_t i = b; i < e; ++i) {
-        const int32_t v = rowptr[i];
-        rowptr[i] = run < cap ? run : cap;
-        run += v;
+    for (int64_t i = b; i < e; i += 8) {
+        int32_t v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = i + q < e ? rowptr[i + q] : 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (i + q < e) rowptr[i + q] = run < cap ? run : cap;
+            run += v[q];
+        }
     }
     if (tid == 0) {
         rowptr[n] = total < cap ? total : cap;
