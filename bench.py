@@ -17,9 +17,13 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
+# the host driver only supports dmabuf IPC: without this RCCL's cross-process buffer sharing fails (already exported on
+# the GPU boxes; set here too so that a bare `torchrun bench.py` from another shell behaves the same)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
