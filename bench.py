@@ -235,6 +235,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         out = one_step(args.warmup + k)
+    enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3      # host time to issue a step (GPU-bound when < ms_per_step)
     barrier()
     elapsed = time.perf_counter() - t0
     phases = {k: float(np.mean(v)) for k, v in model.phase_times_ms().items()}
@@ -269,7 +270,8 @@ def main():
         traffic = None
     if args.rehearse_world > 1:
         print(json.dumps({"rehearsal": f"rank {plan.rank} of {plan.world}, collectives replaced by no-ops, one GPU",
-                          "ms_per_step": ms_per_step, "phases_ms": phases, "pairs_this_rank": pairs_here,
+                          "ms_per_step": ms_per_step, "host_enqueue_ms_per_step": enqueue_ms, "phases_ms": phases,
+                          "pairs_this_rank": pairs_here,
                           "pair_TFLOPs": achieved}))
         return
     if rank == 0:
@@ -286,7 +288,7 @@ def main():
                        "layer inputs, h, E rows and X over RCCL"},
             "pair_scores_per_sec": P / (elapsed / args.steps),
             "pair_phase_scores_per_sec": pairs_here * (world if plan else 1) / (pair_ms * 1e-3),
-            "phases_ms_rank0": phases,
+            "phases_ms_rank0": phases, "host_enqueue_ms_per_step_rank0": enqueue_ms,
             "roofline": {"kernel": "gm::k_pair_score_sample", "bound": "mfma", "achieved": achieved,
                          "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
                          "traffic": traffic, "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch_rank0": pairs_here,
