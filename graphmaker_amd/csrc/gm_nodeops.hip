@@ -220,6 +220,37 @@ __global__ void k_broadcast_row(int64_t n, int w, const float* __restrict__ row,
     if (g >= n * w) return;
     dst[(g / w) * ldd + (g % w)] = row[g % w];
 }
+// mlp_in_t (model/gnn.py:116-120,153) on the one time row, Linear(1,ht)+ReLU then Linear(ht,ht)+ReLU in gm_linear's
+// arithmetic (fmaf chain over ascending k from 0, then + bias), recomputed by every block and written into the h_t
+// columns of two row-major buffers: one launch instead of two one-row GEMMs and two broadcasts.
+__global__ void __launch_bounds__(256)
+k_time_embed(int ht, const float* __restrict__ t, const float* __restrict__ W0, const float* __restrict__ b0,
+             const float* __restrict__ W1, const float* __restrict__ b1, int64_t rows, float* __restrict__ dst1, int64_t ld1,
+             float* __restrict__ dst2, int64_t ld2) {
+    __shared__ float a0[256], a1[256];
+    const int tid = threadIdx.x;
+    if (tid < ht) {
+        float v = __builtin_fmaf(t[0], W0[tid], 0.0f) + b0[tid];
+        if (!(v > 0.0f)) v = 0.0f;
+        a0[tid] = v;
+    }
+    __syncthreads();
+    if (tid < ht) {
+        float acc = 0.0f;
+        for (int k = 0; k < ht; ++k) acc = __builtin_fmaf(a0[k], W1[tid * ht + k], acc);
+        float v = acc + b1[tid];
+        if (!(v > 0.0f)) v = 0.0f;
+        a1[tid] = v;
+    }
+    __syncthreads();
+    const int64_t total = rows * ht;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + tid; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = g / ht;
+        const int c = (int)(g - r * ht);
+        dst1[r * ld1 + c] = a1[c];
+        dst2[r * ld2 + c] = a1[c];
+    }
+}
 __global__ void k_copy2d(int64_t n, int w, const float* __restrict__ src, int64_t lds_, float* __restrict__ dst, int64_t ldd) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n * w) return;
@@ -244,6 +275,15 @@ int launch_gather_rows(int64_t n, int w, const int32_t* idx, const float* table,
 }
 int launch_broadcast_row(int64_t n, int w, const float* row, float* dst, int64_t ldd, hipStream_t s) {
     hipLaunchKernelGGL(k_broadcast_row, dim3((unsigned)((n * w + 255) / 256)), dim3(256), 0, s, n, w, row, dst, ldd);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+int launch_time_embed(int ht, const float* t, const float* W0, const float* b0, const float* W1, const float* b1, int64_t rows,
+                      float* dst1, int64_t ld1, float* dst2, int64_t ld2, hipStream_t s) {
+    GM_REQUIRE(ht > 0 && ht <= 256, "hidden_t out of range for the fused time embedding");
+    int64_t blocks = (rows * ht + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_time_embed, dim3((unsigned)blocks), dim3(256), 0, s, ht, t, W0, b0, W1, b1, rows, dst1, ld1, dst2, ld2);
     GM_LAUNCH_CHECK();
     return GM_OK;
 }

@@ -112,12 +112,17 @@ int tower_ctx(TowerCtx& c, const gm_tower_dims* d, const float* const* P, int64_
 int tower_input(const TowerCtx& c, const float* t_float, const float* X_one_hot, const int32_t* Y, int64_t r0, int64_t r1) {
     const float* const* P = c.P;
     const int64_t rows = r1 - r0;
-    GM_TRY(gm_linear(1, c.ht, 1, t_float, 1, P[0], 1, P[1], c.ht0, c.ht, 1, c.stream));
-    GM_TRY(gm_linear(1, c.ht, c.ht, c.ht0, c.ht, P[2], c.ht, P[3], c.ht1, c.ht, 1, c.stream));
     if (rows <= 0) return GM_OK;
     const int64_t in_X = c.d->in_X;
-    GM_TRY(launch_broadcast_row(rows, c.ht, c.ht1, c.hcat + r0 * c.Hc + c.offT, c.Hc, c.s));
-    GM_TRY(launch_broadcast_row(rows, c.ht, c.ht1, c.agg + r0 * c.ka + c.hX + c.hY, c.ka, c.s));
+    if (c.ht <= 256) {   // one launch: both layers of mlp_in_t and the two broadcasts of h_t
+        GM_TRY(launch_time_embed(c.ht, t_float, P[0], P[1], P[2], P[3], rows, c.hcat + r0 * c.Hc + c.offT, c.Hc,
+                                 c.agg + r0 * c.ka + c.hX + c.hY, c.ka, c.s));
+    } else {
+        GM_TRY(gm_linear(1, c.ht, 1, t_float, 1, P[0], 1, P[1], c.ht0, c.ht, 1, c.stream));
+        GM_TRY(gm_linear(1, c.ht, c.ht, c.ht0, c.ht, P[2], c.ht, P[3], c.ht1, c.ht, 1, c.stream));
+        GM_TRY(launch_broadcast_row(rows, c.ht, c.ht1, c.hcat + r0 * c.Hc + c.offT, c.Hc, c.s));
+        GM_TRY(launch_broadcast_row(rows, c.ht, c.ht1, c.agg + r0 * c.ka + c.hX + c.hY, c.ka, c.s));
+    }
     if (X_one_hot) {   // NULL: h_X^0 of these rows is still in the workspace from the previous call with the same X
         GM_TRY(gm_linear(rows, c.hX, in_X, X_one_hot + r0 * in_X, in_X, P[4], in_X, P[5], c.tmpX + r0 * c.hX, c.hX, 1, c.stream));
         GM_TRY(gm_linear(rows, c.hX, c.hX, c.tmpX + r0 * c.hX, c.hX, P[6], c.hX, P[7], c.hcat + r0 * c.Hc, c.Hc, 1, c.stream));
