@@ -159,3 +159,21 @@ def test_pair_workspace_trouble_flag_is_reported():
     ws[64:68].view(torch.int32)[0] = 1
     with pytest.raises(RuntimeError, match="hand-shake"):
         ops.check_pair_workspace(ws)
+
+
+def test_committed_bench_line_follows_the_contract():
+    """profiles/r1_bench_line.json is bench.py's own output on an MI355X: the keys the driver and the judge read."""
+    import json
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r1_bench_line.json")) as fh:
+        d = json.loads(fh.read())
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1 and r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
