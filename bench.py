@@ -238,6 +238,10 @@ def main():
     enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3      # host time to issue a step (GPU-bound when < ms_per_step)
     barrier()
     elapsed = time.perf_counter() - t0
+    # the timed steps never pass through model.sample()/_finish(): read the two sticky device flags here, so that a step
+    # whose pair kernel gave up on an LDS hand-shake, or whose adjacency was truncated, cannot be reported as a valid rate
+    ops.check_pair_workspace(model._pair_ws)
+    model._csr_ws(dev).check()
     phases = {k: float(np.mean(v)) for k, v in model.phase_times_ms().items()}
     model.enable_phase_timing(False)
     if dist.is_initialized():

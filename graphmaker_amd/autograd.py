@@ -17,6 +17,7 @@ import ctypes
 import torch
 
 from . import _lib as L
+from . import ops
 from ._lib import F32, I32, I64, U32, U64, ptr, require, stream_ptr
 
 _scratch_bufs = {}
@@ -211,6 +212,7 @@ class _Embedding(torch.autograd.Function):
         require(idx32, torch.int32, "idx")
         n = idx32.numel()
         Cn, w = weight.shape
+        ops.check_index_range(idx32, Cn, "Y")
         out = torch.empty((n, w), dtype=torch.float32, device=weight.device)
         L.call("gm_embedding_fwd", I64(n), I32(Cn), I32(w), ptr(idx32), ptr(weight), I64(w), ptr(out), I64(w), stream_ptr())
         ctx.save_for_backward(idx32)
@@ -238,6 +240,8 @@ class _HadamardGather(torch.autograd.Function):
         require(src, torch.int64, "src")
         require(dst, torch.int64, "dst")
         B, d = src.numel(), h.shape[1]
+        ops.check_index_range(src, h.shape[0], "src")
+        ops.check_index_range(dst, h.shape[0], "dst")
         out = torch.empty((B, d), dtype=torch.float32, device=h.device)
         L.call("gm_hadamard_gather", I64(B), I64(d), ptr(src), ptr(dst), ptr(h), I64(d), ptr(out), I64(d), stream_ptr())
         ctx.save_for_backward(h, src, dst)

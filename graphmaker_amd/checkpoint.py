@@ -4,6 +4,7 @@
     {"dataset", "train_yaml_data", "best_val_nll", "best_epoch_X", "best_epoch_E",
      "pred_X_state_dict", "pred_E_state_dict"}
 """
+import numpy
 import torch
 import yaml
 
@@ -53,10 +54,21 @@ def build_model(yaml_data, X_marginal, Y_marginal, E_marginal, num_nodes):
                       **yaml_data["diffusion"]).to(X_marginal.device)
 
 
+def _numpy_scalar_globals():
+    """The data-only numpy globals a reference checkpoint needs: train_sync.py:150-181 stores best_val_nll as the
+    numpy.float64 that np.mean returns, pickled as numpy.core.multiarray.scalar(dtype, bytes) (numpy 1.x module path; numpy 2
+    writes numpy._core).  Reconstructing a scalar from a dtype and raw bytes executes nothing from the file."""
+    scalar = numpy._core.multiarray.scalar if hasattr(numpy, "_core") else numpy.core.multiarray.scalar
+    dtypes = [getattr(numpy.dtypes, n) for n in ("Float64DType", "Float32DType", "Int64DType", "Int32DType")
+              if hasattr(getattr(numpy, "dtypes", None), n)]
+    return [scalar, (scalar, "numpy.core.multiarray.scalar"), (scalar, "numpy._core.multiarray.scalar"), numpy.dtype] + dtypes
+
+
 def load_checkpoint(path, X_marginal, Y_marginal, E_marginal, num_nodes):
-    """sample.py:26-81.  torch.load(weights_only=True): tensors, dicts and scalars only, nothing is unpickled into
-    code.  Returns (model in eval mode, checkpoint dict)."""
-    state = torch.load(path, map_location="cpu", weights_only=True)
+    """sample.py:26-81.  torch.load(weights_only=True): tensors, dicts and scalars only (numpy scalars included), nothing
+    is unpickled into code.  Returns (model in eval mode, checkpoint dict)."""
+    with torch.serialization.safe_globals(_numpy_scalar_globals()):
+        state = torch.load(path, map_location="cpu", weights_only=True)
     for key in ("train_yaml_data", "pred_X_state_dict", "pred_E_state_dict"):
         if key not in state:
             raise KeyError(f"{path}: not a GraphMaker checkpoint (no {key!r})")

@@ -3,6 +3,8 @@
 //                              (:884-894 via BaseModel.posterior :351-406) and sample_X (:214-237) in one pass,
 //                              writing the uint8 state and (optionally) the (n,2F) float one-hot the towers read.
 //   gm_prior_Y / gm_prior_X / gm_prior_E : model/diffusion.py:831-844 (sample_E :188-212 keeps diagonal draws).
+#include <mutex>
+
 #include "gm_common.h"
 
 namespace gm {
@@ -151,4 +153,50 @@ extern "C" int gm_prior_E(int64_t n, int64_t wpr, float p0, float p1, const floa
                        upper_ws);
     GM_LAUNCH_CHECK();
     return gm_symmetrize_upper(n, wpr, upper_ws, bits, stream);
+}
+
+// ---- gm_prior_E without any allocation (include/graphmaker_hip.h: no counterpart in the reference) ----
+// The upper-triangle scratch bitmap that gm_prior_E takes from its caller lives in a file-scope device array here.  Every
+// GPU the library runs on holds its own copy at its own address until the process ends; host code never uses the array's
+// name as a pointer (it is a host-side stand-in, not a device address): the address is looked up once per device with
+// hipGetSymbolAddress and kept in g_static_upper[].
+namespace {
+constexpr int64_t STATIC_MAX_N = 16384;                                   // largest graph the static scratch serves
+constexpr int64_t STATIC_WORDS = STATIC_MAX_N * (STATIC_MAX_N / 32);     // 8,388,608 words = 32 MiB per GPU
+constexpr int STATIC_MAX_DEVICES = 64;
+static __device__ __align__(256) uint32_t scratch[STATIC_WORDS];
+uint32_t* g_static_upper[STATIC_MAX_DEVICES] = {};
+std::mutex g_static_mutex;
+
+// address of this device's copy of `scratch` (the current device must be the one the stream belongs to)
+int static_upper_ptr(uint32_t** out) {
+    int dev = -1;
+    GM_HIP(hipGetDevice(&dev));
+    GM_REQUIRE(dev >= 0 && dev < STATIC_MAX_DEVICES, "device ordinal %d outside the static scratch table", dev);
+    std::lock_guard<std::mutex> lock(g_static_mutex);
+    if (!g_static_upper[dev]) {
+        void* p = nullptr;
+        GM_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        GM_REQUIRE(p && aligned(p, 256), "hipGetSymbolAddress returned a null or misaligned scratch address");
+        g_static_upper[dev] = static_cast<uint32_t*>(p);
+    }
+    *out = g_static_upper[dev];
+    return GM_OK;
+}
+}  // namespace
+
+extern "C" int gm_prior_E_static(int64_t n, int64_t wpr, float p0, float p1, const float* u, uint64_t seed, uint32_t* bits,
+                                 gm_stream_t stream) {
+    GM_REQUIRE(n > 0 && wpr >= (n + 31) / 32 && wpr % 4 == 0 && bits, "bad arguments");
+    GM_REQUIRE(n <= STATIC_MAX_N && n * wpr <= STATIC_WORDS,
+               "gm_prior_E_static serves graphs of at most %lld nodes (n*wpr <= %lld words of static scratch); got n=%lld wpr=%lld: "
+               "use gm_prior_E with a caller-owned workspace", (long long)STATIC_MAX_N, (long long)STATIC_WORDS, (long long)n,
+               (long long)wpr);
+    uint32_t* upper = nullptr;
+    if (int rc = static_upper_ptr(&upper)) return rc;
+    // k_prior_E_upper writes every one of the n*wpr words it is given, so nothing of the previous call's contents survives
+    // in the part this call reads: the scratch needs no clearing
+    hipLaunchKernelGGL(k_prior_E_upper, dim3(blocks_for(n * wpr)), dim3(256), 0, as_stream(stream), n, wpr, p0, p1, u, seed, upper);
+    GM_LAUNCH_CHECK();
+    return gm_symmetrize_upper(n, wpr, upper, bits, stream);
 }

@@ -231,8 +231,19 @@ class BaseModel(nn.Module):
         """argmax of the (B,2) one-hot rows as uint8 (LossE, model/diffusion.py:138)."""
         return (batch_E_one_hot[:, 1] > batch_E_one_hot[:, 0]).to(torch.uint8).contiguous()
 
-    def _kl_tables(self, ns, t, marginal_host, device):
-        """(Q_t, Q_bar_s) as (ntab,4) device tensors for denoise_match (model/diffusion.py:332-341, 681-690)."""
+    @staticmethod
+    def _kl_time_index(t, T):
+        """The time index denoise_match_E/X actually use (model/diffusion.py:332, :681): they do not receive t but
+        t_float = t / T (a float32 division, :587) and recover t = int(t_float.item() * T) in double precision, which
+        truncates to t-1 for some (t, T) -- e.g. T=6 (cora / amazon_photo Async T_X), t=5 -> 4.  Reproduced as is: the
+        validation terms select checkpoints (train_sync.py:150-181), so they have to equal the reference's."""
+        return int(float(np.float32(t) / np.float32(T)) * T)
+
+    def _kl_tables(self, ns, t, marginal_host, device, T=None):
+        """(Q_t, Q_bar_s) as (ntab,4) device tensors for denoise_match (model/diffusion.py:332-341, 681-690).
+        T: the schedule length, to recover the index the way the reference does (_kl_time_index)."""
+        if T is not None:
+            t = self._kl_time_index(t, T)
         Qt = _transition(ns.alphas_host[t], marginal_host).reshape(-1, 4)
         Qs = _transition(ns.alpha_bars_host[t - 1], marginal_host).reshape(-1, 4)
         return torch.from_numpy(Qt).to(device), torch.from_numpy(Qs).to(device)
@@ -390,9 +401,9 @@ class ModelSync(BaseModel):
             A_t = ops.adjacency_from_bitmap(bits_t, n)
             logit_X, logit_E = self.graph_encoder(t_float, x_t_onehot, Y, A_t, src, dst)
             e_t = ops.bitmap_lookup(bits_t, n, src, dst)                              # E_t[batch_src, batch_dst] :765
-            QtE, QsE = self._kl_tables(ns, t_int, self.transition.E_marginal_host, dev)
+            QtE, QsE = self._kl_tables(ns, t_int, self.transition.E_marginal_host, dev, T=self.T)
             dm_E.append(ops.denoise_match2(logit_E, e_t, e0, QtE, QsE).item())
-            QtX, QsX = self._kl_tables(ns, t_int, self.transition.X_marginal_host, dev)
+            QtX, QsX = self._kl_tables(ns, t_int, self.transition.X_marginal_host, dev, T=self.T)
             dm_X.append(ops.denoise_match2(logit_X, x_t, x0, QtX, QsX).item())
         denoise_match_E = float(np.mean(dm_E)) * self.T
         denoise_match_X = float(np.mean(dm_X)) * self.T
@@ -563,7 +574,7 @@ class ModelAsync(BaseModel):
         for t_sample in range(1, self.T_X + 1):
             t_int, t_float, x_t, x_t_onehot = self._apply_noise_X_state(X_one_hot_3d, t_sample, seed)
             logit_X = self.graph_encoder.pred_X(t_float, x_t_onehot, Y)
-            QtX, QsX = self._kl_tables(self.noise_schedule_X, t_int, self.transition.X_marginal_host, dev)
+            QtX, QsX = self._kl_tables(self.noise_schedule_X, t_int, self.transition.X_marginal_host, dev, T=self.T_X)
             dm_X.append(ops.denoise_match2(logit_X, x_t, x0, QtX, QsX).item())
         denoise_match_X = float(np.mean(dm_X)) * self.T_X
         for t_sample in range(1, self.T_E + 1):
@@ -571,7 +582,7 @@ class ModelAsync(BaseModel):
             A_t = ops.adjacency_from_bitmap(bits_t, n)
             logit_E = self.graph_encoder.pred_E(t_float, X_one_hot_2d, Y, A_t, src, dst)
             e_t = ops.bitmap_lookup(bits_t, n, src, dst)
-            QtE, QsE = self._kl_tables(self.noise_schedule_E, t_int, self.transition.E_marginal_host, dev)
+            QtE, QsE = self._kl_tables(self.noise_schedule_E, t_int, self.transition.E_marginal_host, dev, T=self.T_E)
             dm_E.append(ops.denoise_match2(logit_E, e_t, e0, QtE, QsE).item())
         denoise_match_E = float(np.mean(dm_E)) * self.T_E
         loss_X, loss_E = self.log_p_t(X_one_hot_3d, E_one_hot, Y, X_one_hot_2d, src, dst, batch_E_one_hot, 0, 0, seed=seed)

@@ -38,6 +38,15 @@ class _TowerBase(nn.Module):
     _layers_attr = None
     _is_mlp = False
 
+    def _dropout(self):
+        """This tower's dropout stream, re-keyed whenever torch.manual_seed() has changed the global seed."""
+        base = torch.initial_seed()
+        st = getattr(self, "_dropout_state", None)
+        if st is None or getattr(self, "_dropout_base", None) != base:
+            st = self._dropout_state = ag.DropoutState(base + 0x9E3779B97F4A7C15 * self._tower_id)
+            self._dropout_base = base
+        return st
+
     def _build(self, num_attrs_X, num_classes_X, num_classes_Y, hidden_t, hidden_X, hidden_Y, out_size, num_layers,
                dropout):
         in_X = num_attrs_X * num_classes_X
@@ -55,6 +64,10 @@ class _TowerBase(nn.Module):
         self._ptr_key = None
         self._ptr_arr = None
         self._ws = None
+        # dropout masks are Philox(seed, call, element): the containers (GNN / GNNAsymm) give each of their towers its own
+        # key, otherwise pred_X and pred_E.gnn_encoder (same hidden sizes in every reference config) would draw identical
+        # masks step after step
+        self._tower_id = 0
 
     # ---- C-ABI plumbing
     def _ordered_params(self):
@@ -105,8 +118,7 @@ class _TowerBase(nn.Module):
         h_t_exp = h_t.expand(n, -1)
         hX_list, hY_list = [h_X], [h_Y]
         hX_w = h_X.shape[1]
-        if not hasattr(self, "_dropout_state"):
-            self._dropout_state = ag.DropoutState(torch.initial_seed())
+        dropout_state = self._dropout()
         for layer in getattr(self, self._layers_attr):
             if self._is_mlp:                                                                   # model/gnn.py:386-392
                 in_X, in_Y = torch.cat([h_X, h_Y, h_t_exp], dim=1), h_Y
@@ -117,8 +129,8 @@ class _TowerBase(nn.Module):
             h_X = ag.update_block(in_X, ux[0].weight, ux[0].bias, ux[2].weight, ux[2].bias, ux[2].eps)
             h_Y = ag.update_block(in_Y, uy[0].weight, uy[0].bias, uy[2].weight, uy[2].bias, uy[2].eps)
             if self.training:
-                h_X = ag.dropout(h_X, ux[3].p, self._dropout_state)
-                h_Y = ag.dropout(h_Y, uy[3].p, self._dropout_state)
+                h_X = ag.dropout(h_X, ux[3].p, dropout_state)
+                h_Y = ag.dropout(h_Y, uy[3].p, dropout_state)
             hX_list.append(h_X)
             hY_list.append(h_Y)
         h_cat = torch.cat(hX_list + hY_list + [h_t_exp], dim=1)
@@ -259,6 +271,7 @@ class GNN(nn.Module):
         self.pred_X = GNNTower(num_attrs_X, num_classes_X, num_classes_Y, out_size=num_attrs_X * num_classes_X,
                                node_mode=True, **gnn_X_config)
         self.pred_E = LinkPredictor(num_attrs_X, num_classes_X, num_classes_Y, num_classes_E, **gnn_E_config)
+        self.pred_X._tower_id, self.pred_E.gnn_encoder._tower_id = 1, 2
 
     def forward(self, t_float, X_t_one_hot, Y, A_t, batch_src, batch_dst):
         logit_X = self.pred_X(t_float, X_t_one_hot, Y, A_t)
@@ -273,6 +286,7 @@ class GNNAsymm(nn.Module):
         super().__init__()
         self.pred_X = MLPTower(num_attrs_X, num_classes_X, num_classes_Y, **mlp_X_config)
         self.pred_E = LinkPredictor(num_attrs_X, num_classes_X, num_classes_Y, num_classes_E, **gnn_E_config)
+        self.pred_X._tower_id, self.pred_E.gnn_encoder._tower_id = 1, 2
 
     def forward(self, t_float_X, t_float_E, X_t_one_hot, Y, X_one_hot_2d, A_t, batch_src, batch_dst):
         logit_X = self.pred_X(t_float_X, X_t_one_hot, Y)

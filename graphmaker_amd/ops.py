@@ -8,6 +8,26 @@ from . import _lib as L
 from ._lib import F32, I32, I64, U32, U64, ptr, require, stream_ptr, words_per_row
 
 
+# Index arguments that come from the caller (labels, pair lists) are range-checked on the host before a kernel indexes with
+# them: the reference's nn.Embedding / tensor indexing raise on a bad index, an unchecked kernel would read out of bounds.
+# One small reduction + host read per NEW tensor (identity and version are remembered); set to False to skip.
+VALIDATE_INDICES = True
+_validated = {}
+
+
+def check_index_range(t, hi, what):
+    """Raise IndexError unless every entry of the integer tensor t lies in [0, hi)."""
+    if not VALIDATE_INDICES or t.numel() == 0:
+        return
+    key = (what, t.data_ptr(), t._version, t.numel(), int(hi))
+    if _validated.get(what) == key:
+        return
+    lo_v, hi_v = int(t.min().item()), int(t.max().item())
+    if lo_v < 0 or hi_v >= hi:
+        raise IndexError(f"{what}: values span [{lo_v}, {hi_v}], valid range is [0, {hi})")
+    _validated[what] = key
+
+
 class Adjacency:
     """What get_adj (model/diffusion.py:239-256) returns here: the row-normalised adjacency D^-1 A in CSR form with
     implicit values 1/deg[row], plus the symmetric bitmap it was built from."""
@@ -161,6 +181,7 @@ def tower_forward(dims, param_ptrs, n, t_float, X_one_hot, Y32, adj, workspace, 
         if X_one_hot.shape != (n, dims.in_X):
             raise ValueError(f"X_t_one_hot is {tuple(X_one_hot.shape)}, expected {(n, dims.in_X)}")
     dev = Y32.device
+    check_index_range(Y32, dims.num_classes_Y, "Y")
     if out is None:
         out = torch.empty((n, dims.out_size), dtype=torch.float32, device=dev)
     hcat = torch.empty((n, dims.hidden_cat), dtype=torch.float32, device=dev) if want_hcat else None
@@ -177,6 +198,8 @@ def tower_stage(dims, param_ptrs, n, stage, rows, workspace, *, t_float=None, X_
     """One row-sharded stage of a tower (gm_tower_stage): -1 input projections, 0..L-1 layers, L output MLP."""
     rowptr = adj.rowptr if adj is not None else None
     colidx = adj.colidx if adj is not None else None
+    if stage == -1 and Y32 is not None:
+        check_index_range(Y32, dims.num_classes_Y, "Y")
     L.call("gm_tower_stage", C.byref(dims), param_ptrs, I64(n), I32(stage), I64(rows[0]), I64(rows[1]), ptr(t_float),
            ptr(X_one_hot), ptr(Y32), ptr(rowptr), ptr(colidx), ptr(layer_src), ptr(layer_dst), ptr(out), ptr(workspace),
            C.c_size_t(workspace.numel()), stream_ptr())
@@ -187,6 +210,8 @@ def hadamard_gather(h, src, dst):
     require(src, torch.int64, "src")
     require(dst, torch.int64, "dst")
     B, d = src.numel(), h.shape[1]
+    check_index_range(src, h.shape[0], "src")
+    check_index_range(dst, h.shape[0], "dst")
     out = torch.empty((B, d), dtype=torch.float32, device=h.device)
     L.call("gm_hadamard_gather", I64(B), I64(d), ptr(src), ptr(dst), ptr(h), I64(d), ptr(out), I64(d), stream_ptr())
     return out
@@ -298,6 +323,16 @@ def prior_E(n, p0, p1, device, *, seed=0, u=None):
     return bits
 
 
+def prior_E_static(n, p0, p1, bits, *, seed=0, u=None):
+    """gm_prior_E_static: the prior draw into a caller-owned bitmap with the library's own static scratch (no allocation
+    anywhere in the call; n <= 16384)."""
+    require(bits, torch.int32, "bits")
+    if bits.shape != (n, words_per_row(n)):
+        raise ValueError(f"bits is {tuple(bits.shape)}, expected {(n, words_per_row(n))}")
+    L.call("gm_prior_E_static", I64(n), I64(bits.shape[1]), F32(p0), F32(p1), ptr(u), U64(seed), ptr(bits), stream_ptr())
+    return bits
+
+
 # ------------------------------------------------------------------ forward noising / training-side converters
 def noise_E(n, bits0, Q_bar_t, *, seed=0, step=0, u=None):
     """q(E^t | E): symmetric bitmap of E_t (model/diffusion.py:591-594).  Q_bar_t: 4 host floats Q[r*2+c]."""
@@ -356,6 +391,8 @@ def bitmap_lookup(bits, n, i, j):
     require(bits, torch.int32, "bits")
     require(i, torch.int64, "i")
     require(j, torch.int64, "j")
+    check_index_range(i, n, "i")
+    check_index_range(j, n, "j")
     out = torch.empty(i.numel(), dtype=torch.uint8, device=bits.device)
     L.call("gm_bitmap_lookup", I64(n), I64(bits.shape[1]), ptr(bits), I64(i.numel()), ptr(i), ptr(j), ptr(out), stream_ptr())
     return out

@@ -169,6 +169,15 @@ int gm_prior_X(int64_t n, int64_t F, const float* X_marginal, const float* u, ui
 /* upper_ws: scratch bitmap (n*wpr words); bits: symmetric result incl. diagonal draws */
 int gm_prior_E(int64_t n, int64_t wpr, float p0, float p1, const float* u, uint64_t seed, uint32_t* upper_ws,
                uint32_t* bits, gm_stream_t stream);
+/* gm_prior_E for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  It has NO counterpart in the reference.  Same result as gm_prior_E bit for bit; the scratch
+ * bitmap `upper_ws` is a 32 MiB array inside the library (one copy per GPU, held until the process ends) instead of an
+ * argument, and the call allocates nothing.  Limit: n <= 16384 and n*wpr <= 8,388,608 words -- larger graphs get
+ * GM_E_INVALID and must use gm_prior_E.  Every call on a GPU shares that GPU's array: two calls that overlap on one GPU
+ * (different streams, different threads) race; calls on one stream are ordered.  The array keeps the previous call's
+ * contents, which never matter: a call overwrites every word it later reads. */
+int gm_prior_E_static(int64_t n, int64_t wpr, float p0, float p1, const float* u, uint64_t seed, uint32_t* bits,
+                      gm_stream_t stream);
 
 /* ---- forward noising q(G^t | G): model/diffusion.py:559-604 (Sync apply_noise), :962-1033 (Async apply_noise_X/_E) ----
  * Philox streams 5 (E, idx = i*n+j for j >= i, diagonal drawn and kept like sample_E :188-212) and 6 (X, idx = f*n+v);

@@ -30,6 +30,19 @@ CASES = {
                        gnn_X=dict(hidden_t=16, hidden_X=512, hidden_Y=64, num_gnn_layers=2, dropout=0.0),
                        gnn_E=dict(hidden_t=16, hidden_X=512, hidden_Y=64, hidden_E=128, num_gnn_layers=2,
                                   dropout=0.0)),
+    # the step counts of the shipped Async configs (configs/cora|amazon_photo/train_Async.yaml: T_X=6, T_E=9).  T_X=6 is the
+    # one schedule length on which the reference's denoise_match_X recovers a truncated time index (t=5 -> 4,
+    # model/diffusion.py:681), so its val_step fixture pins that behaviour
+    "async_T6": dict(variant="Async", N=60, F=9, C=3, T_X=6, T_E=9, density=0.08, seed=15,
+                     mlp_X=dict(hidden_t=8, hidden_X=32, hidden_Y=16, num_mlp_layers=2, dropout=0.0),
+                     gnn_E=dict(hidden_t=8, hidden_X=32, hidden_Y=16, hidden_E=128, num_gnn_layers=2,
+                                dropout=0.0)),
+    # the amazon_computer Async denoiser (configs/amazon_computer/train_Async.yaml:4-21): MLPTower with hidden_X=1024
+    # (hidden_cat 3280), T_X=7, T_E=9, at a small node count
+    "async_wide": dict(variant="Async", N=96, F=40, C=10, T_X=7, T_E=9, density=0.05, seed=16,
+                       mlp_X=dict(hidden_t=16, hidden_X=1024, hidden_Y=64, num_mlp_layers=2, dropout=0.0),
+                       gnn_E=dict(hidden_t=16, hidden_X=512, hidden_Y=64, hidden_E=128, num_gnn_layers=2,
+                                  dropout=0.0)),
 }
 
 
@@ -122,7 +135,7 @@ def case_json(name):
 
 
 # ---------------------------------------------------------------- training fixtures (tools/gen_golden_train.py)
-TRAIN_CASES = ("sync_small", "async_mid")
+TRAIN_CASES = ("sync_small", "async_mid", "async_T6")
 
 
 def real_graph(cfg):

@@ -125,7 +125,10 @@ def test_symmetrize_bit_exact(dev, n):
 
 
 # ------------------------------------------------------------------ building blocks
-@pytest.mark.parametrize("n,d,density", [(67, 48, 0.1), (300, 576, 0.02), (300, 64, 0.0), (129, 20, 0.3)])
+@pytest.mark.parametrize("n,d,density", [(67, 48, 0.1), (300, 576, 0.02), (300, 64, 0.0), (129, 20, 0.3),
+                                         # n >= 4096 with a dense operand larger than an L2: the XCD-sliced kernel of the
+                                         # headline bench (d=576: sliced leading 512 columns + plain kernel for the tail)
+                                         (8192, 576, 4e-3), (8192, 512, 4e-3), (4100, 640, 1e-2)])
 def test_spmm_mean(dev, n, d, density):
     ops = _ops()
     _, ref_bits = random_sym_bits(n, density, 7 * n + d)
@@ -143,7 +146,10 @@ def test_spmm_mean(dev, n, d, density):
                                              (70, 65, 3, True, True), (129, 130, 33, False, True), (64, 64, 98, True, True),
                                              (1, 1, 4097, False, True),
                                              # 128x128 / 8-wave configuration (>= 400 tiles) with ragged edges in M, N, K
-                                             (3000, 2310, 70, True, True), (2700, 2400, 37, False, False)])
+                                             (3000, 2310, 70, True, True), (2700, 2400, 37, False, False),
+                                             # the same configuration with a K long enough for its steady-state loop
+                                             # (two register sets, step_fast) and a ragged last k-tile: the mlp_out shape
+                                             (3000, 2310, 1744, True, True), (2600, 2500, 1101, False, True)])
 def test_linear(dev, M, N, K, relu, bias):
     ops = _ops()
     rs = np.random.RandomState(M + N + K)
@@ -312,7 +318,7 @@ def test_attribute_step_vs_reference_and_oracle(dev, name):
         np.testing.assert_array_equal(x_s.cpu().numpy(), g[f"x{t}_X_out"])
 
 
-@pytest.mark.parametrize("name", ["sync_small", "sync_mid", "async_mid"])
+@pytest.mark.parametrize("name", ["sync_small", "sync_mid", "async_mid", "async_T6", "async_wide"])
 def test_sample_matches_reference_trajectory(dev, name):
     cfg, g, model, *_ = _models(name, dev)
     N, F = cfg["N"], cfg["F"]
@@ -533,8 +539,8 @@ def test_full_size_step_properties_and_oracle_bands(dev, n, F, ht):
     np.testing.assert_array_equal(ops.onehot_from_x(x1).cpu().numpy(), oh1.cpu().numpy())
     np.testing.assert_array_equal(ops.x_from_onehot(oh1).cpu().numpy(), x1.cpu().numpy())
 
-    # oracle on the same inputs: towers on all nodes are too slow for CI at this size -> check h/logits through the
-    # pair bands and an attribute redraw instead
+    # oracle on the same inputs: pair-matrix bands on the GPU's h, attribute redraw on the GPU's logits, then both towers
+    # on all nodes (end of the test), which closes the chain
     sdE = {k: v.detach().cpu().numpy() for k, v in model.graph_encoder.pred_E.state_dict().items()}
     pair = orc.PairMLP(sdE["mlp_out.0.weight"], sdE["mlp_out.0.bias"], sdE["mlp_out.2.weight"], sdE["mlp_out.2.bias"])
     A_t = ops.adjacency_from_bitmap(bits, n)
@@ -560,14 +566,14 @@ def test_full_size_step_properties_and_oracle_bands(dev, n, F, ht):
     np.testing.assert_array_equal(x1.cpu().numpy(), o_x)
     x_u, _ = ops.attr_posterior_sample(logits, x, t_(tab_X, dev), u=t_(orc.uniform_X(seed, t, n, F), dev))
     np.testing.assert_array_equal(x_u.cpu().numpy(), o_x)
-    # tower outputs of 5 sampled nodes against the oracle needs the whole graph: do it at Cora size only
-    if n <= 3000:
-        sdX = {k: v.detach().cpu().numpy() for k, v in model.graph_encoder.pred_X.state_dict().items()}
-        towerE = orc.Tower.from_state_dict(sdE, is_mlp=False, prefix="gnn_encoder.")
-        towerX = orc.Tower.from_state_dict(sdX, is_mlp=False)
-        rp, ci = orc.csr_from_bitmap(bits_host, n)
-        check_float(h, towerE.forward(np.float32(1.0), oh.cpu().numpy(), Y32.cpu().numpy(), rp, ci), LOGIT_ATOL, "edge tower, full size")
-        check_float(logits, towerX.forward(np.float32(1.0), oh.cpu().numpy(), Y32.cpu().numpy(), rp, ci), LOGIT_ATOL, "node tower, full size")
+    # both towers on ALL nodes against the oracle, bit for bit (at 13752 nodes this is the only place where the XCD-sliced
+    # SpMM and the 128x128 GEMM configuration are compared with the oracle inside the step the bench times)
+    sdX = {k: v.detach().cpu().numpy() for k, v in model.graph_encoder.pred_X.state_dict().items()}
+    towerE = orc.Tower.from_state_dict(sdE, is_mlp=False, prefix="gnn_encoder.")
+    towerX = orc.Tower.from_state_dict(sdX, is_mlp=False)
+    rp, ci = orc.csr_from_bitmap(bits_host, n)
+    check_float(h, towerE.forward(np.float32(1.0), oh.cpu().numpy(), Y32.cpu().numpy(), rp, ci), LOGIT_ATOL, "edge tower, full size")
+    check_float(logits, towerX.forward(np.float32(1.0), oh.cpu().numpy(), Y32.cpu().numpy(), rp, ci), LOGIT_ATOL, "node tower, full size")
 
 
 def _cora_model(variant, dev, seed):

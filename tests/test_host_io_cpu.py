@@ -73,6 +73,41 @@ def test_checkpoint_roundtrip_and_yaml(tmp_path):
         ckpt.build_model(bad, Xm, Ym, Em, cfg["N"])
 
 
+@pytest.mark.parametrize("numpy1_path", [False, True])
+def test_checkpoint_written_the_way_the_reference_writes_it_loads(tmp_path, numpy1_path):
+    """train_sync.py:150-181 stores best_val_nll = np.mean(...) -- a numpy.float64 -- straight into the dict it torch.saves.
+    The weights-only loader must take it (numpy-scalar reconstruction is data only), under numpy 2's module path and under
+    the numpy.core path that the reference's pinned numpy 1.x wrote."""
+    import zipfile
+    cfg = gu.CASES["sync_small"]
+    ypath = os.path.join(str(tmp_path), "train_Sync.yaml")
+    with open(ypath, "w") as fh:
+        fh.write(SYNC_YAML)
+    y = ckpt.load_train_yaml(ypath)
+    Xm, Ym, Em = (torch.from_numpy(a) for a in gu.marginals(cfg))
+    sdX, sdE = gu.make_checkpoint(cfg)
+    path = os.path.join(str(tmp_path), "Sync_T3.pth")
+    torch.save({"dataset": "toy", "train_yaml_data": y, "best_val_nll": np.mean([1.0, 1.5]), "best_epoch_X": 3,
+                "best_epoch_E": 4, "pred_X_state_dict": {k: torch.from_numpy(v) for k, v in sdX.items()},
+                "pred_E_state_dict": {k: torch.from_numpy(v) for k, v in sdE.items()}}, path)
+    if numpy1_path:
+        old = os.path.join(str(tmp_path), "numpy1.pth")
+        with zipfile.ZipFile(path) as zin, zipfile.ZipFile(old, "w") as zout:
+            for it in zin.infolist():
+                data = zin.read(it.filename)
+                if it.filename.endswith("data.pkl"):
+                    assert b"numpy._core.multiarray" in data
+                    data = data.replace(b"numpy._core.multiarray", b"numpy.core.multiarray")
+                zout.writestr(it, data)
+        path = old
+    with pytest.raises(Exception):
+        torch.load(path, weights_only=True)                # the bare loader refuses the numpy scalar ...
+    model, state = ckpt.load_checkpoint(path, Xm, Ym, Em, cfg["N"])      # ... ours takes it, still weights-only
+    assert float(state["best_val_nll"]) == 1.25 and state["best_epoch_E"] == 4
+    for k, v in model.graph_encoder.pred_X.state_dict().items():
+        assert np.array_equal(v.numpy(), sdX[k]), k
+
+
 def test_sampling_without_a_gpu_fails_loudly():
     cfg = gu.CASES["sync_small"]
     Xm, Ym, Em = (torch.from_numpy(a) for a in gu.marginals(cfg))
