@@ -111,7 +111,18 @@ def cpu_baseline(wl, model, state, budget_rows=768, threads=None):
     # every 32768-pair batch): the encoder time measured above times the batch count -- derived, not run (hours)
     nbatch = -(-P // 32768)
     as_ref_s = t_tower_e * nbatch + t_pair * P / p_sample + t_tower_x
-    return {"value": 1.0 / step_s, "unit": "steps/s", "cores": orc.get_threads(), "kind": "port",
+    # the reference's own ModelSync.sample() cannot run on the GPU box (no reference code travels): its figure is the one
+    # measured in the build container by tools/gen_golden.py at Cora shape, quoted beside the port
+    ref = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "ref_cpu_cora_sync.json")) as fh:
+            r = json.load(fh)
+        ref = {"source": "profiles/ref_cpu_cora_sync.json (build container, not this box)", "workload": "cora shape N=2708 F=1433",
+               "steps_per_sec": r["steps_per_sec"], "pair_scores_per_sec": r["pair_scores_per_sec"],
+               "torch_threads": r["torch_threads"], "encoder_runs_per_step": r["encoder_runs_per_step"]}
+    except Exception:
+        pass
+    return {"value": 1.0 / step_s, "unit": "steps/s", "cores": orc.get_threads(), "kind": "port", "reference_cpu": ref,
             "pair_scores_per_sec": p_sample / t_pair,
             "as_reference_cost_structure": {"steps_per_sec": 1.0 / as_ref_s, "encoder_runs_per_step": nbatch,
                                             "note": "derived: measured encoder time x ceil(P/32768) batches + pair stage + "
@@ -265,13 +276,18 @@ def main():
     pairs_here = P if plan is None else plan.pairs_of(plan.rank)
     achieved = FLOP_PER_PAIR * pairs_here / (pair_ms * 1e-3) / 1e12
 
-    traffic = None          # HBM bytes per launch of the pair kernel, from the committed PMC passes of this same command
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1_pmc_summary.json")) as fh:
-            traffic = json.load(fh)["_derived"]["pair_kernel_hbm_traffic_bytes_per_launch"] \
-                if world == 1 and wl["name"] == "amazon_computer" else None
-    except Exception:
-        traffic = None
+    # HBM bytes per launch of the pair kernel: PMC counters cannot be read from inside this process, so the figure is the
+    # one the committed rocprofv3 --pmc passes of this same command produced (tools/profile_bench.sh); its file is named
+    traffic, traffic_source = None, None
+    for cand in ("r2_pmc_summary.json", "r1_pmc_summary.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", cand)) as fh:
+                if world == 1 and wl["name"] == "amazon_computer":
+                    traffic = json.load(fh)["_derived"]["pair_kernel_hbm_traffic_bytes_per_launch"]
+                    traffic_source = f"profiles/{cand} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, not this run)"
+            break
+        except Exception:
+            continue
     if args.rehearse_world > 1:
         print(json.dumps({"rehearsal": f"rank {plan.rank} of {plan.world}, collectives replaced by no-ops, one GPU",
                           "ms_per_step": ms_per_step, "host_enqueue_ms_per_step": enqueue_ms, "phases_ms": phases,
@@ -295,11 +311,22 @@ def main():
             "phases_ms_rank0": phases, "host_enqueue_ms_per_step_rank0": enqueue_ms,
             "roofline": {"kernel": "gm::k_pair_score_sample", "bound": "mfma", "achieved": achieved,
                          "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
-                         "traffic": traffic, "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch_rank0": pairs_here,
+                         "traffic": traffic, "traffic_source": traffic_source, "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch_rank0": pairs_here,
                          "launch_ms": pair_ms},
         }
         if world == 1 and not args.no_extras:
             res["roofline_secondary"] = secondary_rooflines(wl, model, bits, dev)
+            # both towers as they run inside the timed step: their GEMM FLOP over the tower_E + tower_X phase time
+            hX, hY, ht, Fa = wl["gnn_E"]["hidden_X"], wl["gnn_E"]["hidden_Y"], wl["gnn_E"]["hidden_t"], wl["F"]
+            Hc = 3 * (hX + hY) + ht
+            common = 2 * Fa * hX + hX * hX + 2 * ((hX + hY + ht) * hX + hY * hY) + Hc * Hc
+            tower_flop = 2.0 * n * (2 * common + Hc * 128 + Hc * 2 * Fa)
+            tower_ms = phases.get("tower_E", float("nan")) + phases.get("tower_X", float("nan"))
+            tf = tower_flop / (tower_ms * 1e-3) / 1e12
+            res["roofline_secondary"].append(
+                {"kernel": "both denoiser towers inside the step (all gm::k_linear launches + SpMM + LayerNorm + movers)",
+                 "bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "frac": tf / F32_MFMA_PEAK_TFLOPS, "traffic": None, "launch_ms": tower_ms, "flop": tower_flop})
         if full_sample_ms is not None:
             res["full_sample_ms"] = full_sample_ms
         if not args.no_cpu_baseline and world == 1:

@@ -46,10 +46,24 @@ CASES = {
 }
 
 
+# BASELINE.json-sized cases: the reference runs them once in the build container (tools/gen_golden.py), only the sampled
+# states of every step are stored (edge lists, bit-packed attributes); not part of CASES (whose fixtures hold every
+# intermediate tensor and every pair's logits)
+LARGE_CASES = {
+    # BASELINE.json configs[0]: Cora shape with configs/cora/train_Sync.yaml hyper-parameters
+    "cora_sync": dict(variant="Sync", N=2708, F=1433, C=7, T=3, density=1.44e-3, seed=21, x_p1=(0.002, 0.02),
+                      edge_bias=3.0, attr_bias=2.0,
+                      gnn_X=dict(hidden_t=32, hidden_X=512, hidden_Y=64, num_gnn_layers=2, dropout=0.0),
+                      gnn_E=dict(hidden_t=32, hidden_X=512, hidden_Y=64, hidden_E=128, num_gnn_layers=2,
+                                 dropout=0.0)),
+}
+
+
 def marginals(cfg):
     rs = np.random.RandomState(cfg["seed"] + 1000)
     F, C = cfg["F"], cfg["C"]
-    p1 = rs.uniform(0.05, 0.3, size=F).astype(np.float32)
+    lo, hi = cfg.get("x_p1", (0.05, 0.3))
+    p1 = rs.uniform(lo, hi, size=F).astype(np.float32)
     X_marginal = np.stack([1.0 - p1, p1], axis=1).astype(np.float32)
     y = rs.uniform(0.5, 1.5, size=C)
     Y_marginal = (y / y.sum()).astype(np.float32)
@@ -90,13 +104,15 @@ def tower_state_dict(rs, in_X, C, hidden_t, hidden_X, hidden_Y, num_layers, out_
     return sd
 
 
-def make_checkpoint(cfg, edge_bias=2.0, attr_bias=1.0):
+def make_checkpoint(cfg, edge_bias=None, attr_bias=None):
     """Returns (pred_X_state_dict, pred_E_state_dict) as name -> float32 ndarray, reference key names.
 
     Output biases are shifted so the generated graphs stay sparse-ish along the trajectory (a trained
     model's regime) instead of the p=0.5 coin flips an untrained head gives."""
     rs = np.random.RandomState(cfg["seed"])
     F, C = cfg["F"], cfg["C"]
+    edge_bias = cfg.get("edge_bias", 2.0) if edge_bias is None else edge_bias
+    attr_bias = cfg.get("attr_bias", 1.0) if attr_bias is None else attr_bias
     if cfg["variant"] == "Sync":
         g = cfg["gnn_X"]
         sdX = tower_state_dict(rs, 2 * F, C, g["hidden_t"], g["hidden_X"], g["hidden_Y"],
@@ -166,3 +182,26 @@ def train_uniforms(cfg, kind, t):
     rs = np.random.RandomState(cfg["seed"] + 4000 + 17 * t + (0 if kind == "E" else 7))
     n = cfg["N"] * cfg["N"] if kind == "E" else cfg["N"] * cfg["F"]
     return (rs.randint(0, 1 << 24, size=n).astype(np.float32) * np.float32(2.0 ** -24)).astype(np.float32)
+
+
+# ---------------------------------------------------------------- BASELINE.json-sized fixtures (LARGE_CASES)
+def large_bits(n, upper_nz, diag=None):
+    """Symmetric uint32 bitmap (n, wpr) of an upper edge list (+ optional diagonal entries: the prior keeps them)."""
+    wpr = ((n + 31) // 32 + 3) // 4 * 4
+    bits = np.zeros((n, wpr), np.uint32)
+    i, j = upper_nz[:, 0].astype(np.int64), upper_nz[:, 1].astype(np.int64)
+    np.bitwise_or.at(bits, (i, j >> 5), np.uint32(1) << (j & 31).astype(np.uint32))
+    np.bitwise_or.at(bits, (j, i >> 5), np.uint32(1) << (i & 31).astype(np.uint32))
+    if diag is not None and len(diag):
+        d = diag.astype(np.int64)
+        np.bitwise_or.at(bits, (d, d >> 5), np.uint32(1) << (d & 31).astype(np.uint32))
+    return bits
+
+
+def large_x(packed, F):
+    """(N,F) uint8 attributes from the bit-packed rows of a large fixture."""
+    return np.ascontiguousarray(np.unpackbits(packed, axis=1)[:, :F])
+
+
+def upper_bit(bits, i, j):
+    return (bits[i, j >> 5] >> (j & 31).astype(np.uint32)) & 1

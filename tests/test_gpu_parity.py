@@ -628,6 +628,64 @@ def test_cora_size_whole_sample_bit_identical_to_oracle(dev, variant):
     assert 0 < len(ei) < n * 200, "degenerate graph: the comparison would be vacuous"
 
 
+def test_cora_size_steps_and_sample_against_the_reference(dev):
+    """BASELINE.json configs[0]/[1] shape: the reference's own ModelSync.sample() at N=2708, F=1433 with the hidden sizes of
+    configs/cora/train_Sync.yaml (fixture cora_sync, generated by tools/gen_golden.py from /root/reference).  Every reverse
+    step is teacher-forced from the reference's input state; a draw may differ from the reference only within KNIFE of its
+    threshold (counted, none expected); then the free-running sample() must end in the reference's final graph."""
+    import graphmaker_amd as gm
+    ops = _ops()
+    cfg = gu.LARGE_CASES["cora_sync"]
+    g = gu.load_golden("cora_sync")
+    N, F, T, seed = cfg["N"], cfg["F"], cfg["T"], cfg["seed"]
+    Xm, Ym, Em = gu.marginals(cfg)
+    sdX, sdE = gu.make_checkpoint(cfg)
+    model = gm.ModelSync(T=T, X_marginal=t_(Xm, dev), Y_marginal=t_(Ym, dev), E_marginal=t_(Em, dev),
+                         gnn_X_config=cfg["gnn_X"], gnn_E_config=cfg["gnn_E"], num_nodes=N)
+    model.graph_encoder.pred_X.load_state_dict({k: torch.from_numpy(v) for k, v in sdX.items()})
+    model.graph_encoder.pred_E.load_state_dict({k: torch.from_numpy(v) for k, v in sdE.items()})
+    model = model.to(dev).eval()
+    Y32 = t_(g["Y"], dev)
+    iu, ju = np.triu_indices(N, 1)
+    W1, b1, W2, b2 = model.graph_encoder.pred_E.pair_params()
+    flips = 0
+    for t in range(T, 0, -1):
+        bits_in = bits_t(gu.large_bits(N, g[f"e{t}_E_in_upper_nz"], g[f"e{t}_E_in_diag"]), dev)
+        x_in = t_(gu.large_x(g[f"e{t}_X_in_bits"], F), dev)
+        oh_in = ops.onehot_from_x(x_in)
+        x_s, _, bits_s = model.denoise_step(t, x_in, oh_in, Y32, bits_in, seed)
+        want = gu.large_bits(N, g[f"e{t}_E_out_upper_nz"])
+        got = bits_np(bits_s)
+        if not np.array_equal(got, want):
+            bad = np.flatnonzero(gu.upper_bit(got, iu, ju) != gu.upper_bit(want, iu, ju))
+            tab_E, _ = model.step_tables(t)
+            t_float = torch.tensor([t / T], dtype=torch.float32, device=dev)
+            h = model.graph_encoder.pred_E.gnn_encoder(t_float, oh_in, Y32, ops.adjacency_from_bitmap(bits_in, N))
+            _, _, po = ops.pair_score_sample(h, W1, b1, W2, b2, bits_in, tab_E, seed=seed, step=t, want_debug=True)
+            po = po.cpu().numpy()[bad]
+            u = orc.uniform_E(seed, t, N)[bad]
+            far = np.abs(u * (po[:, 0] + po[:, 1]) - po[:, 1]) > KNIFE
+            assert not far.any(), f"t={t}: {int(far.sum())} edge draws differ away from their threshold"
+            flips += len(bad)
+        x_ref = gu.large_x(g[f"x{t}_X_out_bits"], F)
+        v, f = np.nonzero(x_s.cpu().numpy() != x_ref)
+        if len(v):
+            _, tab_X = model.step_tables(t)
+            t_float = torch.tensor([t / T], dtype=torch.float32, device=dev)
+            logits = model.graph_encoder.pred_X._run(t_float, oh_in, Y32, ops.adjacency_from_bitmap(bits_in, N))
+            _, _, pX = ops.attr_posterior_sample(logits, x_in, t_(tab_X, dev), seed=seed, step=t, want_debug=True)
+            pX = pX.cpu().numpy()[v, f]
+            u = orc.uniform_X(seed, t, N, F)[f * N + v]
+            far = np.abs(u * (pX[:, 0] + pX[:, 1]) - pX[:, 1]) > KNIFE
+            assert not far.any(), f"t={t}: {int(far.sum())} attribute draws differ away from their threshold"
+            flips += len(v)
+    assert flips == 0, f"{flips} threshold-level flips vs the reference (allowed by tolerance, not expected)"
+    X, Y1h, el = model.sample(seed=seed, dense=False)
+    np.testing.assert_array_equal(Y1h.argmax(1).cpu().numpy(), g["Y"])
+    np.testing.assert_array_equal(X[:, :, 1].T.cpu().numpy().astype(np.uint8), gu.large_x(g["final_X_bits"], F))
+    np.testing.assert_array_equal(el.cpu().numpy().T, g["final_E_upper_nz"])
+
+
 def test_sbm100k_structure_step_bands(dev):
     """BASELINE.json config 4 scale (N = 100,000; 5e9 pairs): one pass of the pair kernel on a single GPU, checked
     against the oracle on row bands; exercises 64-bit pair ranks, 1.2 M tiles and the 1.25 GB bitmaps."""

@@ -275,12 +275,123 @@ def run_case(name, gnn, diffusion):
           f"final nnz={nE} X ones={int(out['final_X'].sum())}")
 
 
+def _upper_nz(E):
+    """(m,2) int32 list of the i<j entries of a symmetric dense matrix, row-major."""
+    return torch.triu(E, diagonal=1).nonzero().numpy().astype(np.int32)
+
+
+def run_large_case(name, gnn, diffusion):
+    """A BASELINE.json-sized Sync case (gu.LARGE_CASES): the reference's own ModelSync.sample() (model/diffusion.py:797-905)
+    under the shared-RNG shim.  Stored: Y, the prior state, and per reverse step the sampled state going in and coming out
+    (upper edge lists, bit-packed attributes) -- what a teacher-forced step needs -- plus the final sample.  Then the same
+    model is sampled once more UNMODIFIED (torch.multinomial, no hooks) and timed: profiles/ref_cpu_<name>.json is the
+    reference's CPU path on this container's cores (SURVEY.md 8d "CPU baseline")."""
+    import json
+    import time
+    cfg = gu.LARGE_CASES[name]
+    N, F, T = cfg["N"], cfg["F"], cfg["T"]
+    Xm, Ym, Em = gu.marginals(cfg)
+    sdX, sdE = gu.make_checkpoint(cfg)
+    model = diffusion.ModelSync(T=T, X_marginal=torch.from_numpy(Xm), Y_marginal=torch.from_numpy(Ym),
+                                E_marginal=torch.from_numpy(Em), gnn_X_config=cfg["gnn_X"], gnn_E_config=cfg["gnn_E"],
+                                num_nodes=N)
+    model.graph_encoder.pred_X.load_state_dict(to_t(sdX))
+    model.graph_encoder.pred_E.load_state_dict(to_t(sdE))
+    model.eval()
+    out = {}
+    Ctx.seed, Ctx.N, Ctx.F = cfg["seed"], N, F
+    Ctx.site, Ctx.e_step, Ctx.x_step = "Y", 0, 0
+    orig = dict(sample_E=model.sample_E, sample_X=model.sample_X, sample_E_infer=model.sample_E_infer, get_E_t=model.get_E_t)
+    state = {"t": T + 1}
+
+    def pack_x(x_one_hot):     # (N,2F) float one-hot -> bit-packed (N, ceil(F/8)) of the class-1 indicator
+        return np.packbits(x_one_hot.reshape(N, F, 2)[:, :, 1].numpy().astype(np.uint8), axis=1)
+
+    def sample_E(prob):
+        Ctx.site = "E_prior"
+        r = orig["sample_E"](prob)
+        Ctx.site = "Y"
+        out["E_T_upper_nz"] = _upper_nz(r)
+        out["E_T_diag"] = torch.diagonal(r).nonzero().reshape(-1).numpy().astype(np.int32)
+        return r
+
+    def sample_X(prob):
+        Ctx.site = "X"
+        r = orig["sample_X"](prob)
+        Ctx.site = "Y"
+        out[f"x{Ctx.x_step}_X_out_bits"] = pack_x(r)
+        return r
+
+    def sample_E_infer(prob):
+        Ctx.site = "E"
+        r = orig["sample_E_infer"](prob)
+        Ctx.site = "Y"
+        return r
+
+    def get_E_t(device, loader, pred_E_func, t_float, X_t_one_hot, Y_0, E_t, *rest):
+        t = int(round(float(t_float.item()) * T))
+        Ctx.e_step = Ctx.x_step = t
+        out[f"e{t}_E_in_upper_nz"] = _upper_nz(E_t)
+        out[f"e{t}_E_in_diag"] = torch.diagonal(E_t).nonzero().reshape(-1).numpy().astype(np.int32)
+        out[f"e{t}_X_in_bits"] = pack_x(X_t_one_hot)
+        A_t, E_s = orig["get_E_t"](device, loader, pred_E_func, t_float, X_t_one_hot, Y_0, E_t, *rest)
+        out[f"e{t}_E_out_upper_nz"] = _upper_nz(E_s)
+        return A_t, E_s
+
+    model.sample_E, model.sample_X, model.sample_E_infer, model.get_E_t = sample_E, sample_X, sample_E_infer, get_E_t
+    saved = torch.Tensor.multinomial
+    torch.Tensor.multinomial = _shim_multinomial
+    try:
+        X, Y1h, E = model.sample(batch_size=32768, num_workers=0)
+    finally:
+        torch.Tensor.multinomial = saved
+    out["Y"] = Y1h.argmax(1).numpy().astype(np.int32)
+    out["final_X_bits"] = np.packbits(X[:, :, 1].T.contiguous().numpy().astype(np.uint8), axis=1)
+    out["final_E_upper_nz"] = _upper_nz(E)
+    out["config_json"] = np.frombuffer(json.dumps(cfg, sort_keys=True).encode(), dtype=np.uint8)
+    np.savez_compressed(gu.golden_path(name), **out)
+    print(f"{name}: wrote {gu.golden_path(name)} ({os.path.getsize(gu.golden_path(name)) / 1e3:.0f} kB); edges per step "
+          f"{[len(out[f'e{t}_E_out_upper_nz']) for t in range(T, 0, -1)]}")
+
+    # ---- the unmodified reference, timed (no shim, no state capture; only a stopwatch around get_E_t)
+    for k, v in orig.items():
+        setattr(model, k, v)
+    step_s = []
+
+    def timed_get_E_t(*a):
+        t0 = time.perf_counter()
+        r = orig["get_E_t"](*a)
+        step_s.append(time.perf_counter() - t0)
+        return r
+    model.get_E_t = timed_get_E_t
+    torch.manual_seed(0)
+    t0 = time.perf_counter()
+    model.sample(batch_size=32768, num_workers=0)
+    total = time.perf_counter() - t0
+    P = N * (N - 1) // 2
+    rec = {"what": "the reference's ModelSync.sample() (model/diffusion.py:797-905) run unmodified from /root/reference in the "
+                   "build container (torch CPU, dgl.sparse replaced by the torch stand-in of tools/gen_golden.py)",
+           "config": {k: cfg[k] for k in ("N", "F", "C", "T")}, "hidden": cfg["gnn_E"], "pairs_per_step": P,
+           "torch_threads": torch.get_num_threads(), "cpu_count": os.cpu_count(), "torch": torch.__version__,
+           "sample_wall_s": total, "get_E_t_wall_s_per_step": step_s,
+           "steps_per_sec": T / total, "structure_steps_per_sec": 1.0 / float(np.mean(step_s)),
+           "pair_scores_per_sec": P / float(np.mean(step_s)),
+           "encoder_runs_per_step": -(-P // 32768)}
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    with open(os.path.join(ROOT, "profiles", f"ref_cpu_{name}.json"), "w") as fh:
+        json.dump(rec, fh, indent=1)
+    print(json.dumps(rec))
+
+
 def main():
     torch.set_grad_enabled(False)
     gnn, diffusion = load_reference()
     names = sys.argv[1:] or list(gu.CASES)
     for name in names:
-        run_case(name, gnn, diffusion)
+        if name in gu.LARGE_CASES:
+            run_large_case(name, gnn, diffusion)
+        else:
+            run_case(name, gnn, diffusion)
 
 
 if __name__ == "__main__":
