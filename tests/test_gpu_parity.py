@@ -576,6 +576,176 @@ def test_full_size_step_properties_and_oracle_bands(dev, n, F, ht):
     check_float(logits, towerX.forward(np.float32(1.0), oh.cpu().numpy(), Y32.cpu().numpy(), rp, ci), LOGIT_ATOL, "node tower, full size")
 
 
+def test_eight_rank_shards_reproduce_single_gpu_step_at_amazon_computer_size(dev):
+    """BASELINE.json configs[3]: the 8-rank plan at N=13752 (no 8-GPU box here).  All 8 ranks' tower stages, folded pair
+    chunks and attribute rows are run one after the other on this GPU into shared buffers -- what the all-gathers
+    assemble -- and must equal the single-GPU step bit for bit."""
+    import graphmaker_amd as gm
+    from graphmaker_amd.parallel import ShardPlan
+    ops = _ops()
+    n, F, C, world = 13752, 767, 10, 8
+    rs = np.random.RandomState(8)
+    p1 = rs.uniform(0.002, 0.02, size=F).astype(np.float32)
+    Xm = np.stack([1 - p1, p1], 1).astype(np.float32)
+    Ym = np.full(C, 1.0 / C, np.float32)
+    Em = np.array([1 - 2.6e-3, 2.6e-3], np.float32)
+    cfgX = dict(hidden_t=16, hidden_X=512, hidden_Y=64, num_gnn_layers=2, dropout=0.0)
+    torch.manual_seed(8)
+    model = gm.ModelSync(T=3, X_marginal=t_(Xm, dev), Y_marginal=t_(Ym, dev), E_marginal=t_(Em, dev), gnn_X_config=cfgX,
+                         gnn_E_config=dict(hidden_E=128, **cfgX), num_nodes=n)
+    with torch.no_grad():
+        model.graph_encoder.pred_E.mlp_out[2].bias += torch.tensor([3.0, -3.0])
+    model = model.to(dev).eval()
+    seed, T = 31, 3
+    Y32 = ops.prior_Y(n, t_(Ym, dev), seed=seed)
+    bits = ops.prior_E(n, float(Em[0]), float(Em[1]), dev, seed=seed)
+    x_in, X_oh = ops.prior_X(n, t_(Xm, dev), seed=seed)
+    A_t = ops.adjacency_from_bitmap(bits, n)
+    t_float = torch.tensor([1.0], dtype=torch.float32, device=dev)
+    tab_E, tab_X = model.step_tables(T)
+    enc, pred_X = model.graph_encoder.pred_E.gnn_encoder, model.graph_encoder.pred_X
+    W1, b1, W2, b2 = model.graph_encoder.pred_E.pair_params()
+    h_full = enc(t_float, X_oh, Y32, A_t)
+    up_full = ops.pair_score_sample(h_full, W1, b1, W2, b2, bits, tab_E, seed=seed, step=T)
+    lg_full = pred_X._run(t_float, X_oh, Y32, A_t).clone()
+    xs_full, _ = ops.attr_posterior_sample(lg_full, x_in, t_(tab_X, dev), seed=seed, step=T)
+    x1, _, bits1 = model.denoise_step(T, x_in, X_oh, Y32, bits, seed)            # the step the bench times
+    assert torch.equal(x1, xs_full) and torch.equal(bits1, ops.symmetrize_upper(up_full, n))
+
+    plans = [ShardPlan.make(n, world, r) for r in range(world)]
+    assert plans[0].padded_pair_rows >= n and sum(p.pairs_of(p.rank) for p in plans) == n * (n - 1) // 2
+    h = torch.full_like(h_full, float("nan"))
+    lg = torch.full_like(lg_full, float("nan"))
+    xs = torch.full_like(xs_full, 255)
+    up = torch.zeros((plans[0].padded_pair_rows, up_full.shape[1]), dtype=torch.int32, device=dev)
+
+    def staged(tower, out):
+        d, ptrs, ws = tower._dims, tower._param_ptrs(), tower._workspace(n, dev)
+        bufs = [torch.full((n, d.hidden_X + d.hidden_Y), float("nan"), device=dev) for _ in range(2)]
+        for pl in plans:
+            ops.tower_stage(d, ptrs, n, -1, pl.node_range(), ws, t_float=t_float, X_one_hot=X_oh, Y32=Y32, layer_dst=bufs[0])
+        for l in range(d.num_layers):
+            dst = bufs[(l + 1) & 1] if l + 1 < d.num_layers else None
+            for pl in plans:
+                ops.tower_stage(d, ptrs, n, l, pl.node_range(), ws, adj=A_t, layer_src=bufs[l & 1], layer_dst=dst)
+        for pl in plans:
+            ops.tower_stage(d, ptrs, n, d.num_layers, pl.node_range(), ws, out=out)
+
+    staged(enc, h)
+    staged(pred_X, lg)
+    assert torch.equal(h, h_full) and torch.equal(lg, lg_full)
+    for pl in plans:
+        ops.pair_score_sample(h, W1, b1, W2, b2, bits, tab_E, seed=seed, step=T, row_ranges=pl.pair_chunks(), out_upper=up)
+        ops.attr_posterior_sample(lg, x_in, t_(tab_X, dev), seed=seed, step=T, rows=pl.node_range(), x_s=xs, want_onehot=False)
+    assert torch.equal(ops.symmetrize_upper(up[:n].contiguous(), n), bits1)
+    assert torch.equal(xs, xs_full)
+
+
+def test_amazon_computer_async_attribute_tower_hidden_1024(dev):
+    """configs/amazon_computer/train_Async.yaml:4-21: the MLPTower with hidden_X=1024 (hidden_cat 3280) at N=13752, F=767 --
+    one attribute step of ModelAsync (model/diffusion.py:1330-1358): logits on all nodes and the draw equal the oracle's bit
+    for bit (the 96-node reference fixture of the same denoiser is the case async_wide)."""
+    import graphmaker_amd as gm
+    ops = _ops()
+    n, F, C = 13752, 767, 10
+    rs = np.random.RandomState(9)
+    p1 = rs.uniform(0.002, 0.02, size=F).astype(np.float32)
+    Xm = np.stack([1 - p1, p1], 1).astype(np.float32)
+    Ym = np.full(C, 1.0 / C, np.float32)
+    Em = np.array([1 - 2.6e-3, 2.6e-3], np.float32)
+    torch.manual_seed(9)
+    model = gm.ModelAsync(T_X=7, T_E=9, X_marginal=t_(Xm, dev), Y_marginal=t_(Ym, dev), E_marginal=t_(Em, dev),
+                          mlp_X_config=dict(hidden_t=16, hidden_X=1024, hidden_Y=64, num_mlp_layers=2, dropout=0.0),
+                          gnn_E_config=dict(hidden_t=16, hidden_X=512, hidden_Y=64, hidden_E=128, num_gnn_layers=2, dropout=0.0),
+                          num_nodes=n).to(dev).eval()
+    assert model.graph_encoder.pred_X._dims.hidden_cat == 3280
+    seed, t = 41, 7
+    Y32 = ops.prior_Y(n, t_(Ym, dev), seed=seed)
+    x, oh = ops.prior_X(n, t_(Xm, dev), seed=seed)
+    x_s, oh_s = model.attribute_step(t, x, oh, Y32, seed)
+    t_float = torch.tensor([t / 7], dtype=torch.float32, device=dev)
+    logits = model.graph_encoder.pred_X(t_float, oh, Y32)
+    assert tuple(logits.shape) == (n, F, 2)
+    sdX = {k: v.detach().cpu().numpy() for k, v in model.graph_encoder.pred_X.state_dict().items()}
+    towerX = orc.Tower.from_state_dict(sdX, is_mlp=True)
+    o_logits = towerX.forward(np.float32(t / 7), oh.cpu().numpy(), Y32.cpu().numpy())
+    check_float(logits.reshape(n, 2 * F), o_logits, LOGIT_ATOL, "MLPTower hidden_X=1024 at N=13752")
+    o_x = orc.attr_posterior_sample(o_logits, x.cpu().numpy(), model.table_X(t), seed=seed, step=t)
+    np.testing.assert_array_equal(x_s.cpu().numpy(), o_x)
+    np.testing.assert_array_equal(oh_s.cpu().numpy(), orc.onehot_from_x(o_x))
+
+
+def test_sbm100k_full_sync_step_against_the_oracle(dev):
+    """BASELINE.json configs[4]: one WHOLE Sync reverse step at N=100,000 with Cora-shaped attributes (F=1433) and the
+    hyper-parameters of configs/cora/train_Sync.yaml -- CSR build, both towers on all nodes, all 5e9 pairs, symmetrise,
+    attribute draw.  Oracle: both towers on all nodes bit for bit, the attribute draw on all nodes, bands of pair rows."""
+    import graphmaker_amd as gm
+    ops = _ops()
+    n, F, C = 100_000, 1433, 7
+    rs = np.random.RandomState(10)
+    p1 = rs.uniform(0.002, 0.02, size=F).astype(np.float32)
+    Xm = np.stack([1 - p1, p1], 1).astype(np.float32)
+    Ym = np.full(C, 1.0 / C, np.float32)
+    Em = np.array([1 - 4e-5, 4e-5], np.float32)
+    cfgX = dict(hidden_t=32, hidden_X=512, hidden_Y=64, num_gnn_layers=2, dropout=0.0)
+    torch.manual_seed(10)
+    model = gm.ModelSync(T=3, X_marginal=t_(Xm, dev), Y_marginal=t_(Ym, dev), E_marginal=t_(Em, dev), gnn_X_config=cfgX,
+                         gnn_E_config=dict(hidden_E=128, **cfgX), num_nodes=n)
+    with torch.no_grad():
+        model.graph_encoder.pred_E.mlp_out[2].bias += torch.tensor([4.0, -4.0])
+        bx = model.graph_encoder.pred_X.mlp_out[2].bias
+        bx[0::2] += 2.0
+        bx[1::2] -= 2.0
+    model = model.to(dev).eval()
+    seed, t = 51, 3
+    Y32 = ops.prior_Y(n, t_(Ym, dev), seed=seed)
+    bits = ops.prior_E(n, float(Em[0]), float(Em[1]), dev, seed=seed)
+    x, oh = ops.prior_X(n, t_(Xm, dev), seed=seed)
+    x1, oh1, bits1 = model.denoise_step(t, x, oh, Y32, bits, seed)
+    model._csr_ws(dev).check()
+    ops.check_pair_workspace(model._pair_ws)
+    # structure of the sampled graph without a dense matrix
+    rowptr, colidx = ops.csr_from_bitmap(bits1, n)
+    deg = rowptr[1:] - rowptr[:-1]
+    assert int(rowptr[n]) % 2 == 0 and 0 < int(rowptr[n]) < 40 * n
+    rows = torch.repeat_interleave(torch.arange(n, device=dev), deg.long())
+    assert not bool((rows.int() == colidx).any())                                  # empty diagonal
+    order = torch.argsort(colidx.long() * n + rows)
+    assert torch.equal(rows[order].int(), colidx) and torch.equal(colidx[order].long(), rows)   # symmetric
+    # oracle: towers on all nodes
+    sdE = {k: v.detach().cpu().numpy() for k, v in model.graph_encoder.pred_E.state_dict().items()}
+    sdX = {k: v.detach().cpu().numpy() for k, v in model.graph_encoder.pred_X.state_dict().items()}
+    towerE = orc.Tower.from_state_dict(sdE, is_mlp=False, prefix="gnn_encoder.")
+    towerX = orc.Tower.from_state_dict(sdX, is_mlp=False)
+    pair = orc.PairMLP(sdE["mlp_out.0.weight"], sdE["mlp_out.0.bias"], sdE["mlp_out.2.weight"], sdE["mlp_out.2.bias"])
+    bits_host, oh_np, y_np = bits_np(bits), oh.cpu().numpy(), Y32.cpu().numpy()
+    rp, ci = orc.csr_from_bitmap(bits_host, n)
+    A_t = ops.adjacency_from_bitmap(bits, n)
+    np.testing.assert_array_equal(A_t.rowptr.cpu().numpy(), rp)
+    np.testing.assert_array_equal(A_t.colidx.cpu().numpy(), ci)
+    t_float = torch.tensor([1.0], dtype=torch.float32, device=dev)
+    h = model.graph_encoder.pred_E.gnn_encoder(t_float, oh, Y32, A_t)
+    o_h = towerE.forward(np.float32(1.0), oh_np, y_np, rp, ci)
+    check_float(h, o_h, LOGIT_ATOL, "edge tower at N=100k")
+    logits = model.graph_encoder.pred_X._run(t_float, oh, Y32, A_t)
+    o_logits = towerX.forward(np.float32(1.0), oh_np, y_np, rp, ci)
+    check_float(logits, o_logits, LOGIT_ATOL, "node tower at N=100k")
+    del logits, oh_np
+    tab_E, tab_X = model.step_tables(t)
+    np.testing.assert_array_equal(x1.cpu().numpy(), orc.attr_posterior_sample(o_logits, x.cpu().numpy(), tab_X, seed=seed, step=t))
+    del o_logits
+    # pair rows: the step's E_s (symmetrised) against oracle bands computed from the oracle's h
+    got = bits_np(bits1)
+    nw = (n + 31) // 32
+    for r0, r1 in [(0, 1), (46341, 46342), (65535, 65537), (n - 65, n - 64), (n - 2, n)]:
+        want = orc.pair_score_sample(n, o_h, pair, bits_host, tab_E, seed=seed, step=t, row_begin=r0, row_end=r1)
+        for i in range(r0, r1):
+            w0 = i >> 5
+            keep = np.uint32((0xFFFFFFFF << ((i & 31) + 1)) & 0xFFFFFFFF)
+            assert (got[i, w0] & keep) == want[i, w0]
+            np.testing.assert_array_equal(got[i, w0 + 1:nw], want[i, w0 + 1:nw])
+
+
 def _cora_model(variant, dev, seed):
     """BASELINE.json configs 0/1: Cora shape (N=2708, F=1433, C=7) with the hidden sizes of configs/cora/*.yaml and
     reference-shaped random weights (pre-trained checkpoints are remote fetches)."""
