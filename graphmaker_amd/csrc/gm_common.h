@@ -109,6 +109,16 @@ __device__ __forceinline__ void softmax2(float l0, float l1, float& q0, float& q
     q0 = e0 / s;
     q1 = e1 / s;
 }
+// softmax over two classes from the logit difference d = l1 - l0: instruction-for-instruction the oracle's gmo_softmax2_diff
+__device__ __forceinline__ void softmax2_diff(float d, float& q0, float& q1) {
+    const bool pos = d > 0.0f;
+    const float e = expf_nonpos(pos ? -d : d);
+    const float s = 1.0f + e;
+    const float r = 1.0f / s;
+    const float small = e * r;
+    q0 = pos ? small : r;
+    q1 = pos ? r : small;
+}
 // posterior from the table tab[(i*2+k)*2+e] (model/diffusion.py:351-406 for a one-hot Z_t = e)
 __device__ __forceinline__ void posterior2(const float* tab, int e, float q0, float q1, float& p0, float& p1) {
     float a0 = q0 * tab[0 + e];

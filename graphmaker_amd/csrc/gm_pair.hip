@@ -3,8 +3,8 @@
 // For every unordered pair i<j of the rows this call owns:
 //     z      = h_i * h_j                                   (model/gnn.py:246)
 //     hid    = relu(W1 z + b1)      128x128                (model/gnn.py:227-231,248)
-//     logit  = W2 hid + b2          2x128
-//     q      = softmax(logit)                              (model/diffusion.py:457)
+//     logit  = W2 hid + b2          2x128, evaluated as the difference d = logit[1] - logit[0] (all a 2-class softmax needs)
+//     q      = softmax(logit) = softmax([0, d])            (model/diffusion.py:457)
 //     p      = posterior(q | E_t[i,j])                     (model/diffusion.py:351-406,463) -- 8-entry table
 //     E_s    = draw(p)                                     (model/diffusion.py:421)
 // and the draw goes straight into an upper-triangle bitmap: no (P,2) tensor, no pair index list, no dense N x N.
@@ -215,13 +215,17 @@ __device__ __forceinline__ float relu_bits(float x) {   // max(x, 0) for non-NaN
     return __int_as_float(max(__float_as_int(x), 0));
 }
 
+// DBG = true is the instantiation that also writes both logits of every pair (logits_dbg, for comparison with the
+// reference's LinkPredictor output); the draws and posteriors come from the same logit-difference path in both.
+template <bool DBG>
 __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const PairArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[(HE + 2 * TILE) * LDR + HE + 2 * HE + 32];
+    __shared__ __attribute__((aligned(16))) float lds[(HE + 2 * TILE) * LDR + HE + 3 * HE + 32];
     float* W1s = lds;
     float* hIs = W1s + HE * LDR;
     float* hJs = hIs + TILE * LDR;
     float* b1s = hJs + TILE * LDR;
-    float* W2s = b1s + HE;
+    float* dws = b1s + HE;                         // W2[1] - W2[0]: the second layer is evaluated as a logit difference
+    float* W2s = dws + HE;                         // both rows of W2 (read by the DBG instantiation only)
     int* tile_s = reinterpret_cast<int*>(W2s + 2 * HE);   // tile_s[0..1]: ring of queue items, [2]: items published
     int* stg_s = tile_s + 4;                       // stg_s[w], w < 4: tiles wave w has staged
     int* turn_s = tile_s + 8;                      // turn_s[w]: MFMA row-units wave w has issued so far (hand-off flags)
@@ -238,8 +242,10 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
         put_split(W1s + o * LDR, c4, *reinterpret_cast<const float4*>(a.W1 + o * HE + 4 * c4));
     }
     if (tid < HE) b1s[tid] = a.b1[tid];
+    if (tid < HE) dws[tid] = a.W2[HE + tid] - a.W2[tid];
     if (tid < 2 * HE) W2s[tid] = a.W2[tid];
     const float b20 = a.b2[0], b21 = a.b2[1];
+    const float db = b21 - b20;
 
     if (tid == 0) { tile_s[0] = (int)atomicAdd(a.counter, 1u); tile_s[2] = 0; }
     if (tid < 8) turn_s[tid] = 0;
@@ -360,40 +366,51 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
 #else
                 if (i < row_end && i < a.n) {
 #endif
-                    // ---- second layer: in-lane dot over this lane's 64 hidden units, both strips
-                    float part[2][2];
+                    // ---- second layer as a logit difference d = l1 - l0 = (W2[1] - W2[0]) . relu(hid) + (b2[1] - b2[0])
+                    // (softmax over two classes needs nothing else): in-lane dot over this lane's 64 hidden units, both strips
+                    float part[2];
+                    float dbg0[2] = {0.0f, 0.0f}, dbg1[2] = {0.0f, 0.0f};
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
-                        float l0 = 0.0f, l1 = 0.0f;
+                        float dd = 0.0f;
 #pragma unroll
                         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                             for (int g = 0; g < 4; ++g) {
                                 const int ob = mt * 32 + 8 * g + 4 * half;
-                                const float4 w0 = *reinterpret_cast<const float4*>(W2s + ob);
-                                const float4 w1 = *reinterpret_cast<const float4*>(W2s + HE + ob);
-                                const float w0v[4] = {w0.x, w0.y, w0.z, w0.w};
-                                const float w1v[4] = {w1.x, w1.y, w1.z, w1.w};
+                                const float4 wd = *reinterpret_cast<const float4*>(dws + ob);
+                                const float wdv[4] = {wd.x, wd.y, wd.z, wd.w};
 #pragma unroll
-                                for (int r4 = 0; r4 < 4; ++r4) {
-                                    const float hid = relu_bits(acc[s][mt][4 * g + r4]);
-                                    l0 = __builtin_fmaf(hid, w0v[r4], l0);
-                                    l1 = __builtin_fmaf(hid, w1v[r4], l1);
+                                for (int r4 = 0; r4 < 4; ++r4)
+                                    dd = __builtin_fmaf(relu_bits(acc[s][mt][4 * g + r4]), wdv[r4], dd);
+                                if (DBG) {
+                                    const float4 w0 = *reinterpret_cast<const float4*>(W2s + ob);
+                                    const float4 w1 = *reinterpret_cast<const float4*>(W2s + HE + ob);
+                                    const float w0v[4] = {w0.x, w0.y, w0.z, w0.w};
+                                    const float w1v[4] = {w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+                                    for (int r4 = 0; r4 < 4; ++r4) {
+                                        const float hid = relu_bits(acc[s][mt][4 * g + r4]);
+                                        dbg0[s] = __builtin_fmaf(hid, w0v[r4], dbg0[s]);
+                                        dbg1[s] = __builtin_fmaf(hid, w1v[r4], dbg1[s]);
+                                    }
                                 }
                             }
-                        part[s][0] = l0;
-                        part[s][1] = l1;
+                        part[s] = dd;
                     }
                     // Half-wave h finishes strip h: it keeps its own partial of that strip and receives the partner's
                     // (lane ^ 32) partial of the same strip, so softmax / posterior / draw run once per pair.
-                    const float send0 = half ? part[0][0] : part[1][0];
-                    const float send1 = half ? part[0][1] : part[1][1];
-                    const float recv0 = __shfl_xor(send0, 32), recv1 = __shfl_xor(send1, 32);
-                    const float own0 = half ? part[1][0] : part[0][0];
-                    const float own1 = half ? part[1][1] : part[0][1];
-                    // (hidden units with bit 2 clear) + (bit 2 set), then the bias: the oracle's order
-                    const float L0 = ((half ? recv0 : own0) + (half ? own0 : recv0)) + b20;
-                    const float L1 = ((half ? recv1 : own1) + (half ? own1 : recv1)) + b21;
+                    const float recv = __shfl_xor(half ? part[0] : part[1], 32);
+                    const float own = half ? part[1] : part[0];
+                    // (hidden units with bit 2 clear) + (bit 2 set), then the bias difference: the oracle's order
+                    const float D = ((half ? recv : own) + (half ? own : recv)) + db;
+                    float L0 = 0.0f, L1 = 0.0f;
+                    if (DBG) {
+                        const float r0 = __shfl_xor(half ? dbg0[0] : dbg0[1], 32), r1 = __shfl_xor(half ? dbg1[0] : dbg1[1], 32);
+                        const float o0 = half ? dbg0[1] : dbg0[0], o1 = half ? dbg1[1] : dbg1[0];
+                        L0 = ((half ? r0 : o0) + (half ? o0 : r0)) + b20;
+                        L1 = ((half ? r1 : o1) + (half ? o1 : r1)) + b21;
+                    }
 
                     const int64_t j = j0 + lane;                       // lanes 0-31: strip 0, lanes 32-63: strip 1
                     const int64_t wi = 2 * (int64_t)tj + half;
@@ -402,7 +419,7 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
                     if (wi < a.wpr) etw = a.bits_t[i * a.wpr + wi];
                     const bool e = (etw >> l31) & 1u;
                     float q0, q1;
-                    softmax2(L0, L1, q0, q1);
+                    softmax2_diff(D, q0, q1);
                     const float a0 = q0 * (e ? a.tab[1] : a.tab[0]);
                     const float c0 = q1 * (e ? a.tab[5] : a.tab[4]);
                     const float a1 = q0 * (e ? a.tab[3] : a.tab[2]);
@@ -421,7 +438,7 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
                     }
 #ifndef GM_PAIR_STAMP   // the diagnostic build reuses post_dbg for its stamps
                     if (valid) {
-                        if (a.logits_dbg) { a.logits_dbg[2 * rank] = L0; a.logits_dbg[2 * rank + 1] = L1; }
+                        if (DBG && a.logits_dbg) { a.logits_dbg[2 * rank] = L0; a.logits_dbg[2 * rank + 1] = L1; }
                         if (a.post_dbg) { a.post_dbg[2 * rank] = p0; a.post_dbg[2 * rank + 1] = p1; }
                     }
 #endif
@@ -522,7 +539,8 @@ extern "C" int gm_pair_score_sample_ranges(int64_t n, int64_t hE, const float* h
     a.nfull = (a.ntiles / cus) * cus;
     a.nitems = a.nfull + 8 * (a.ntiles - a.nfull);
     const unsigned grid = (unsigned)(a.nitems < cus ? a.nitems : cus);   // 137 KB of LDS: one workgroup per CU
-    hipLaunchKernelGGL(k_pair_score_sample, dim3(grid), dim3(PAIR_THREADS), 0, s, a);
+    if (logits_dbg) hipLaunchKernelGGL(k_pair_score_sample<true>, dim3(grid), dim3(PAIR_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(k_pair_score_sample<false>, dim3(grid), dim3(PAIR_THREADS), 0, s, a);
     GM_LAUNCH_CHECK();
     return GM_OK;
 }

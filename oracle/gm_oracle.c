@@ -206,6 +206,18 @@ void gmo_softmax2(float l0, float l1, float* p0, float* p1) {
     *p1 = e1 / s;
 }
 
+/* softmax over the two edge classes from the logit DIFFERENCE d = l1 - l0 (model/diffusion.py:457 for 2 classes):
+ * softmax([l0, l1]) = softmax([0, d]); the larger class has exp(0) = 1, so one exp: e = exp(-|d|), r = 1 / (1 + e),
+ * big = r, small = e * r.  The pair kernel computes d directly (one fmaf chain on W2[1] - W2[0]), not two logits. */
+void gmo_softmax2_diff(float d, float* p0, float* p1) {
+    float e = gm_expf_nonpos(d > 0.0f ? -d : d);
+    float s = 1.0f + e;
+    float r = 1.0f / s;
+    float small = e * r;
+    if (d > 0.0f) { *p0 = small; *p1 = r; }
+    else { *p0 = r; *p1 = small; }
+}
+
 /* ------------------------------------------------------------------ priors */
 /* model/diffusion.py:831-833  Y_0 ~ Cat(Y_marginal) */
 void gmo_prior_Y(int64_t n, int C, const float* Y_marginal, const float* u_or_null, uint64_t seed, int32_t* y) {
@@ -537,6 +549,9 @@ void gmo_pair_score_sample(int64_t n, int64_t hE, const float* h, const float* W
     float* W1t = (float*)malloc(sizeof(float) * (size_t)(hE * hE));
     for (int64_t o = 0; o < hE; ++o)
         for (int64_t k = 0; k < hE; ++k) W1t[k * hE + o] = W1[o * hE + k];
+    float dw[1024];
+    for (int64_t o = 0; o < hE; ++o) dw[o] = W2[hE + o] - W2[o];
+    const float db = b2[1] - b2[0];
 #pragma omp parallel for schedule(dynamic, 1)
     for (int64_t i = row_begin; i < row_end; ++i) {
         uint32_t* orow = out_upper + i * wpr;
@@ -578,24 +593,33 @@ void gmo_pair_score_sample(int64_t n, int64_t hE, const float* h, const float* W
             }
             for (int b = 0; b < nj; ++b) {
                 const int64_t j = jb0 + b;
-                float logit[2];
-                for (int c = 0; c < 2; ++c) {
-                    float s[2] = {0.0f, 0.0f};
-                    for (int64_t o = 0; o < hE; ++o) {
-                        float r = hid[b][o] > 0.0f ? hid[b][o] : 0.0f;
-                        int hsel = (int)((o >> 2) & 1);
-                        s[hsel] = fmaf(r, W2[c * hE + o], s[hsel]);
-                    }
-                    logit[c] = (s[0] + s[1]) + b2[c];
+                /* logit difference d = l1 - l0 on dw = W2[1] - W2[0]: (S0 + S1) + (b2[1] - b2[0]), S_h = fmaf chain over
+                 * ascending o with ((o>>2)&1)==h (the split a 32x32 MFMA accumulator tile gives the two half-waves) */
+                float s[2] = {0.0f, 0.0f};
+                for (int64_t o = 0; o < hE; ++o) {
+                    float r = hid[b][o] > 0.0f ? hid[b][o] : 0.0f;
+                    int hsel = (int)((o >> 2) & 1);
+                    s[hsel] = fmaf(r, dw[o], s[hsel]);
                 }
+                const float d = (s[0] + s[1]) + db;
                 float q0, q1, p0, p1;
-                gmo_softmax2(logit[0], logit[1], &q0, &q1);                      /* diffusion.py:457 */
+                gmo_softmax2_diff(d, &q0, &q1);                                  /* diffusion.py:457 */
                 int e_t = (int)((bits_t[i * wpr + (j >> 5)] >> (j & 31)) & 1u);  /* diffusion.py:460-462 */
                 gmo_posterior_apply(tab, e_t, q0, q1, &p0, &p1);                 /* diffusion.py:463-464 */
                 int64_t r = pair_rank(n, i, j);
                 float u = u_or_null ? u_or_null[r] : u_E(seed, step, i, j);
                 if (draw2(u, p0, p1)) orow[j >> 5] |= 1u << (j & 31);            /* diffusion.py:421 */
-                if (logits_dbg) { logits_dbg[2 * r] = logit[0]; logits_dbg[2 * r + 1] = logit[1]; }
+                if (logits_dbg) {      /* both logits (model/gnn.py:248), for comparison with the reference only */
+                    for (int c = 0; c < 2; ++c) {
+                        float t[2] = {0.0f, 0.0f};
+                        for (int64_t o = 0; o < hE; ++o) {
+                            float rl = hid[b][o] > 0.0f ? hid[b][o] : 0.0f;
+                            int hsel = (int)((o >> 2) & 1);
+                            t[hsel] = fmaf(rl, W2[c * hE + o], t[hsel]);
+                        }
+                        logits_dbg[2 * r + c] = (t[0] + t[1]) + b2[c];
+                    }
+                }
                 if (post_dbg) { post_dbg[2 * r] = p0; post_dbg[2 * r + 1] = p1; }
             }
         }

@@ -122,6 +122,7 @@ void gmo_tower_forward(const gmo_tower_dims* d, const float* const* params, int6
 void gmo_pair_logits(int64_t hE, const float* hi, const float* hj, const float* W1, const float* b1,
                      const float* W2, const float* b2, float logit[2]);
 void gmo_softmax2(float l0, float l1, float* p0, float* p1);
+void gmo_softmax2_diff(float d, float* p0, float* p1);
 /* Rows [row_begin,row_end) of the upper triangle.  out_upper: bitmap (n x wpr), only words of those rows
  * are written (bit j of row i for j>i).  logits_dbg/post_dbg: (P,2) indexed by rank, optional. */
 void gmo_pair_score_sample(int64_t n, int64_t hE, const float* h, const float* W1, const float* b1,
