@@ -321,7 +321,8 @@ def main():
             Hc = 3 * (hX + hY) + ht
             common = 2 * Fa * hX + hX * hX + 2 * ((hX + hY + ht) * hX + hY * hY) + Hc * Hc
             tower_flop = 2.0 * n * (2 * common + Hc * 128 + Hc * 2 * Fa)
-            tower_ms = phases.get("tower_E", float("nan")) + phases.get("tower_X", float("nan"))
+            # (the two towers run on two streams beside each other: towers_wall is the time both take together)
+            tower_ms = phases.get("towers_wall", phases.get("tower_E", float("nan")) + phases.get("tower_X", float("nan")))
             tf = tower_flop / (tower_ms * 1e-3) / 1e12
             res["roofline_secondary"].append(
                 {"kernel": "both denoiser towers inside the step (all gm::k_linear launches + SpMM + LayerNorm + movers)",

@@ -171,6 +171,13 @@ class BaseModel(nn.Module):
             ws = self.__dict__["_csr_workspace"] = ops.CsrWorkspace(self.num_nodes, device)
         return ws
 
+    def _side_stream(self, device):
+        """The second stream of the Sync step (attribute branch beside the edge encoder), one per model and device."""
+        st = self.__dict__.get("_side")
+        if st is None or st.device != device:
+            st = self.__dict__["_side"] = torch.cuda.Stream(device=device)
+        return st
+
     def enable_phase_timing(self, on=True):
         self._prof = {} if on else None
 
@@ -263,13 +270,16 @@ class BaseModel(nn.Module):
         return dev
 
     def _structure_step(self, pred_E, t_float, X_one_hot, Y32, bits_t, tab_E, seed, step, u=None, plan=None, group=None,
-                        reuse_X=False):
+                        reuse_X=False, after_csr=None, before_pair=None):
         """get_E_t (model/diffusion.py:428-472): returns (A_t, symmetric bitmap of E_s).
         plan: parallel.ShardPlan for the one-process-per-GPU decomposition (None = single GPU).
-        reuse_X: X_one_hot is the tensor of the previous call (ModelAsync's structure steps): mlp_in_X(X) is not recomputed."""
+        reuse_X: X_one_hot is the tensor of the previous call (ModelAsync's structure steps): mlp_in_X(X) is not recomputed.
+        after_csr(A_t) / before_pair(): hooks of the Sync step, which runs its attribute branch beside the edge encoder."""
         n = self.num_nodes
         with self.phase("csr"):      # built into the model's workspace: no host read of the edge count in a step
             A_t = ops.adjacency_from_bitmap(bits_t, n, workspace=self._csr_ws(bits_t.device))
+        if after_csr is not None:
+            after_csr(A_t)
         enc = pred_E.gnn_encoder
         with self.phase("tower_E"):
             if plan is None:
@@ -288,6 +298,8 @@ class BaseModel(nn.Module):
         ranges = [(0, n)] if plan is None else plan.pair_chunks()
         upper = torch.zeros((n if plan is None else plan.padded_pair_rows, bits_t.shape[1]), dtype=torch.int32,
                             device=h.device)
+        if before_pair is not None:
+            before_pair()
         with self.phase("pair"):      # a rank's two folded chunks go into ONE launch (shared tile queue)
             ops.pair_score_sample(h, W1, b1, W2, b2, bits_t, tab_E, seed=seed, step=step, u=u, row_ranges=ranges,
                                   out_upper=upper, workspace=self._pair_ws)
@@ -423,12 +435,33 @@ class ModelSync(BaseModel):
         uX = uniforms.get(("X", t)) if uniforms else None
         if plan is not None:
             return self._denoise_step_sharded(t, t_float, x, x_onehot, Y32, bits_t, tab_E, tab_X, seed, uE, uX, plan, group)
-        A_t, bits_s = self._structure_step(self.graph_encoder.pred_E, t_float, x_onehot, Y32, bits_t, tab_E, seed, t,
-                                           u=uE, plan=plan, group=group)
-        pred_X = self.graph_encoder.pred_X                                      # A_t of E_t, not E_s (:875-878)
-        x_s, oh_s = self._attribute_draw(self._logits_fn(pred_X, t_float, x_onehot, Y32, A_t, plan, group), x, tab_X,
-                                         seed, t, u=uX, plan=plan, group=group)
-        return x_s, oh_s, bits_s
+        # The attribute branch (node tower + draw) reads the same A_t / X_t / Y as the edge encoder (A_t of E_t, not E_s:
+        # model/diffusion.py:875-878) and nothing of the structure branch, so it is issued on a second stream beside the edge
+        # encoder: its memory-bound kernels (SpMM, LayerNorm, the draw) and the partly empty last rounds of the GEMM grids fill
+        # with the other tower's work.  Both join before the pair kernel, which takes the whole chip.
+        cur = torch.cuda.current_stream(dev)
+        side = self._side_stream(dev)
+        pred_X = self.graph_encoder.pred_X
+        res = {}
+
+        wall = self.phase("towers_wall")        # both towers + the attribute draw as they overlap: CSR done -> joined
+
+        def attribute_branch(A_t):
+            wall.__enter__()
+            side.wait_stream(cur)                                               # A_t (and the step's inputs) are ready
+            with torch.cuda.stream(side):
+                res["x"], res["oh"] = self._attribute_draw(self._logits_fn(pred_X, t_float, x_onehot, Y32, A_t, None, None),
+                                                           x, tab_X, seed, t, u=uX)
+
+        def join():
+            cur.wait_stream(side)
+            wall.__exit__()
+            for v in res.values():            # allocated on the side stream, consumed on this one from here on
+                v.record_stream(cur)
+
+        _, bits_s = self._structure_step(self.graph_encoder.pred_E, t_float, x_onehot, Y32, bits_t, tab_E, seed, t, u=uE,
+                                         after_csr=attribute_branch, before_pair=join)
+        return res["x"], res["oh"], bits_s
 
     def _denoise_step_sharded(self, t, t_float, x, x_onehot, Y32, bits_t, tab_E, tab_X, seed, uE, uX, plan, group):
         """denoise_step on one rank of the one-process-per-GPU decomposition (parallel.py), scheduled so that the
