@@ -16,7 +16,7 @@ EXPORTS = [
     "gm_version", "gm_last_error", "gm_device_cus",
     "gm_bitmap_from_dense_i64", "gm_dense_i64_from_bitmap", "gm_symmetrize_upper", "gm_csr_rowptr", "gm_csr_rowptr_capped", "gm_csr_fill",
     "gm_bitmap_from_upper_edges", "gm_spmm_mean", "gm_linear", "gm_layernorm", "gm_tower_workspace_bytes",
-    "gm_tower_forward", "gm_tower_stage", "gm_hadamard_gather", "gm_pair_score_sample", "gm_pair_score_sample_ranges", "gm_attr_posterior_sample", "gm_onehot_from_x",
+    "gm_tower_forward", "gm_tower_stage", "gm_tower_prep_floats", "gm_tower_prepare", "gm_onehot_prep_floats", "gm_onehot_prepare", "gm_onehot_linear", "gm_hadamard_gather", "gm_pair_score_sample", "gm_pair_score_sample_ranges", "gm_attr_posterior_sample", "gm_onehot_from_x",
     "gm_x_from_onehot", "gm_prior_Y", "gm_prior_X", "gm_prior_E", "gm_prior_E_static",
     "gm_noise_E", "gm_noise_X", "gm_bitmap_from_onehot_f32", "gm_x_from_onehot3d",
     "gm_gemm_workspace_bytes", "gm_gemm", "gm_colsum_workspace_bytes", "gm_colsum", "gm_layernorm_fwd",
@@ -54,7 +54,7 @@ def load():
         lib = C.CDLL(LIB_PATH)
         lib.gm_last_error.restype = C.c_char_p
         lib.gm_version.restype = C.c_int
-        for name in ("gm_gemm_workspace_bytes", "gm_colsum_workspace_bytes", "gm_layernorm_bwd_workspace_bytes",
+        for name in ("gm_tower_prep_floats", "gm_onehot_prep_floats", "gm_gemm_workspace_bytes", "gm_colsum_workspace_bytes", "gm_layernorm_bwd_workspace_bytes",
                      "gm_softmax_ce2_workspace_bytes", "gm_embedding_bwd_workspace_bytes"):
             getattr(lib, name).restype = C.c_int64
         _lib = lib

@@ -111,15 +111,21 @@ class _Mlp2(torch.autograd.Function):
     gradient instead of in a pass of its own (the pair MLP's hidden gradient is batch x 128 floats: 1 GB per step)."""
 
     @staticmethod
-    def forward(ctx, x, W1, b1, W2, b2, relu_out):
+    def forward(ctx, x, W1, b1, W2, b2, relu_out, onehot_sparse=None):
         x, W1, W2 = _c(x), _c(W1), _c(W2)
         require(x, torch.float32, "x")
         M, K = x.shape
         H, N = W1.shape[0], W2.shape[0]
         if W1.shape[1] != K or W2.shape[1] != H:
             raise ValueError(f"mlp2: x is {tuple(x.shape)}, W1 is {tuple(W1.shape)}, W2 is {tuple(W2.shape)}")
-        y1 = torch.empty((M, H), dtype=torch.float32, device=x.device)
-        L.call("gm_linear", I64(M), I64(H), I64(K), ptr(x), I64(K), ptr(W1), I64(K), ptr(b1), ptr(y1), I64(H), I32(1), stream_ptr())
+        if onehot_sparse is not None:
+            # x is the one-hot attribute matrix (mlp_in_X): the first layer in the arithmetic of the fused tower call
+            # (gm_onehot.hip), so that the tape's forward and gm_tower_forward give the same bits; the backward is unchanged
+            y1 = ops.onehot_linear(ops.x_from_onehot(x), W1, b1, relu=True, sparse=bool(onehot_sparse))
+        else:
+            y1 = torch.empty((M, H), dtype=torch.float32, device=x.device)
+            L.call("gm_linear", I64(M), I64(H), I64(K), ptr(x), I64(K), ptr(W1), I64(K), ptr(b1), ptr(y1), I64(H), I32(1),
+                   stream_ptr())
         y2 = torch.empty((M, N), dtype=torch.float32, device=x.device)
         L.call("gm_linear", I64(M), I64(N), I64(H), ptr(y1), I64(H), ptr(W2), I64(H), ptr(b2), ptr(y2), I64(N), I32(int(relu_out)),
                stream_ptr())
@@ -143,7 +149,7 @@ class _Mlp2(torch.autograd.Function):
         db2 = colsum(g) if ctx.has_bias[1] and need[4] else None
         g1 = gemm(False, True, M, H, N, g, N, W2, H, mask=y1)          # (dY W2) where the hidden unit was active
         dx, dW1, db1 = _linear_backward(x, W1, g1, (need[0], need[1], ctx.has_bias[0] and need[2]))
-        return dx, dW1, db1, dW2, db2, None
+        return dx, dW1, db1, dW2, db2, None, None
 
 
 class _UpdateBlock(torch.autograd.Function):
@@ -311,8 +317,10 @@ def linear(x, W, b=None, relu=False):
     return _Linear.apply(x, W, b, relu)
 
 
-def mlp2(x, W1, b1, W2, b2, relu_out=False):
-    return _Mlp2.apply(x, W1, b1, W2, b2, relu_out)
+def mlp2(x, W1, b1, W2, b2, relu_out=False, onehot_sparse=None):
+    """onehot_sparse: None = a general input; False / True = x is the towers' one-hot attribute matrix and the first layer
+    runs in the dense / sparse one-hot form (include/graphmaker_hip.h, gm_onehot_linear)."""
+    return _Mlp2.apply(x, W1, b1, W2, b2, relu_out, onehot_sparse)
 
 
 def update_block(x, W, b, gamma, beta, eps=1e-5):

@@ -32,7 +32,7 @@ extern "C" int gm_device_cus(int* cus) {
 static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct TowerWs {
-    size_t hcat, agg, mid, tmpX, ht0, ht1, total;
+    size_t hcat, agg, mid, tmpX, ht0, ht1, xu8, x01, total;
 };
 static TowerWs tower_layout(const gm_tower_dims* d, int64_t n) {
     const int64_t Hc = (int64_t)(d->num_layers + 1) * (d->hidden_X + d->hidden_Y) + d->hidden_t;
@@ -45,12 +45,16 @@ static TowerWs tower_layout(const gm_tower_dims* d, int64_t n) {
     w.tmpX = off; off += align_up(sizeof(float) * (size_t)(n * d->hidden_X));
     w.ht0 = off;  off += align_up(sizeof(float) * (size_t)d->hidden_t);
     w.ht1 = off;  off += align_up(sizeof(float) * (size_t)d->hidden_t);
+    const int64_t F = d->in_X / 2;
+    w.xu8 = off;  off += align_up((size_t)(n * F));                                   // attributes recovered from a one-hot input
+    w.x01 = off;  off += align_up(sizeof(float) * (size_t)(n * ((F + 3) & ~(int64_t)3)));   // 0/1 matrix of the dense first layer
     w.total = off;
     return w;
 }
 
 static int check_dims(const gm_tower_dims* d, int64_t n) {
     GM_REQUIRE(d, "null dims");
+    GM_REQUIRE(d->in_X % 2 == 0, "in_X = %d: two classes per attribute expected (binary attributes)", d->in_X);
     GM_REQUIRE(n > 0 && d->in_X > 0 && d->num_classes_Y > 0 && d->hidden_t > 0 && d->hidden_X > 0 && d->hidden_Y > 0 &&
                    d->num_layers >= 0 && d->out_size > 0,
                "bad tower dims");
@@ -78,7 +82,8 @@ struct TowerCtx {
     int64_t n;
     gm_stream_t stream;
     hipStream_t s;
-    float *hcat, *agg, *mid, *tmpX, *ht0, *ht1;
+    float *hcat, *agg, *mid, *tmpX, *ht0, *ht1, *x01;
+    uint8_t* xu8;
     int ht, hX, hY, nl;
     int64_t Hc, ka, offY, offT;
 };
@@ -100,6 +105,8 @@ int tower_ctx(TowerCtx& c, const gm_tower_dims* d, const float* const* P, int64_
     c.tmpX = reinterpret_cast<float*>(ws + L.tmpX);
     c.ht0 = reinterpret_cast<float*>(ws + L.ht0);
     c.ht1 = reinterpret_cast<float*>(ws + L.ht1);
+    c.xu8 = reinterpret_cast<uint8_t*>(ws + L.xu8);
+    c.x01 = reinterpret_cast<float*>(ws + L.x01);
     c.ht = d->hidden_t; c.hX = d->hidden_X; c.hY = d->hidden_Y; c.nl = d->num_layers;
     c.Hc = (int64_t)(c.nl + 1) * (c.hX + c.hY) + c.ht;
     c.ka = c.hX + c.hY + c.ht;
@@ -109,7 +116,8 @@ int tower_ctx(TowerCtx& c, const gm_tower_dims* d, const float* const* P, int64_
 }
 
 // input projections for node rows [r0,r1): mlp_in_t, mlp_in_X, emb_Y (model/gnn.py:116-127,153-155) -> h^0 slices of hcat
-int tower_input(const TowerCtx& c, const float* t_float, const float* X_one_hot, const int32_t* Y, int64_t r0, int64_t r1) {
+int tower_input(const TowerCtx& c, const float* t_float, const float* X_one_hot, const uint8_t* x_u8, const float* prep,
+                int sparse_X, const int32_t* Y, int64_t r0, int64_t r1) {
     const float* const* P = c.P;
     const int64_t rows = r1 - r0;
     if (rows <= 0) return GM_OK;
@@ -123,8 +131,18 @@ int tower_input(const TowerCtx& c, const float* t_float, const float* X_one_hot,
         GM_TRY(launch_broadcast_row(rows, c.ht, c.ht1, c.hcat + r0 * c.Hc + c.offT, c.Hc, c.s));
         GM_TRY(launch_broadcast_row(rows, c.ht, c.ht1, c.agg + r0 * c.ka + c.hX + c.hY, c.ka, c.s));
     }
-    if (X_one_hot) {   // NULL: h_X^0 of these rows is still in the workspace from the previous call with the same X
-        GM_TRY(gm_linear(rows, c.hX, in_X, X_one_hot + r0 * in_X, in_X, P[4], in_X, P[5], c.tmpX + r0 * c.hX, c.hX, 1, c.stream));
+    if (X_one_hot || x_u8) {   // both NULL: h_X^0 of these rows is still in the workspace from the previous call with the same X
+        // first layer on the attributes themselves (gm_onehot.hip): a one-hot input is reduced to them first
+        const int64_t F = in_X / 2;
+        GM_REQUIRE(prep, "the tower needs its prepared first layer (gm_tower_prepare)");
+        if (!x_u8) {
+            GM_TRY(gm_x_from_onehot(rows, F, X_one_hot + r0 * in_X, c.xu8 + r0 * F, c.stream));
+            x_u8 = c.xu8;
+        }
+        const int64_t ldF = (F + 3) & ~(int64_t)3;
+        const bool walk = sparse_X && c.hX % 4 == 0 && c.hX <= 2048 && F < 65536;
+        GM_TRY(gm_onehot_linear(rows, F, c.hX, x_u8 + r0 * F, prep, walk ? nullptr : c.x01 + r0 * ldF, c.tmpX + r0 * c.hX, c.hX, 1,
+                                c.stream));
         GM_TRY(gm_linear(rows, c.hX, c.hX, c.tmpX + r0 * c.hX, c.hX, P[6], c.hX, P[7], c.hcat + r0 * c.Hc, c.Hc, 1, c.stream));
     }
     GM_TRY(launch_gather_rows(rows, c.hY, Y + r0, P[8], c.hY, c.hcat + r0 * c.Hc + c.offY, c.Hc, c.s));
@@ -176,17 +194,29 @@ int tower_output(const TowerCtx& c, float* out, int64_t r0, int64_t r1) {
 
 }  // namespace
 
+extern "C" int64_t gm_tower_prep_floats(const gm_tower_dims* d) {
+    if (!d || d->in_X <= 0 || d->in_X % 2 || d->hidden_X <= 0) return -1;
+    return gm_onehot_prep_floats(d->in_X / 2, d->hidden_X);
+}
+
+extern "C" int gm_tower_prepare(const gm_tower_dims* d, const float* const* P, float* prep, gm_stream_t stream) {
+    GM_REQUIRE(d && P && prep && P[4] && P[5], "null pointer");
+    GM_REQUIRE(d->in_X > 0 && d->in_X % 2 == 0 && d->hidden_X > 0, "bad tower dims");
+    return gm_onehot_prepare(d->in_X / 2, d->hidden_X, P[4], P[5], prep, stream);
+}
+
 extern "C" int gm_tower_forward(const gm_tower_dims* d, const float* const* P, int64_t n, const float* t_float,
-                                const float* X_one_hot, const int32_t* Y, const int32_t* rowptr, const int32_t* colidx,
-                                float* out, float* hcat_out, int64_t out_row_begin, int64_t out_row_end, void* workspace,
-                                size_t workspace_bytes, gm_stream_t stream) {
+                                const float* X_one_hot, const uint8_t* x_u8, const float* prep, int sparse_X, const int32_t* Y,
+                                const int32_t* rowptr, const int32_t* colidx, float* out, float* hcat_out,
+                                int64_t out_row_begin, int64_t out_row_end, void* workspace, size_t workspace_bytes,
+                                gm_stream_t stream) {
     TowerCtx c;
     if (int rc = tower_ctx(c, d, P, n, workspace, workspace_bytes, stream)) return rc;
     GM_REQUIRE(t_float && Y && out, "null pointer");
     GM_REQUIRE(d->is_mlp || d->num_layers == 0 || (rowptr && colidx), "GNN tower needs a CSR adjacency");
     GM_REQUIRE(0 <= out_row_begin && out_row_begin <= out_row_end && out_row_end <= n, "bad output row range [%lld,%lld)",
                (long long)out_row_begin, (long long)out_row_end);
-    GM_TRY(tower_input(c, t_float, X_one_hot, Y, 0, n));
+    GM_TRY(tower_input(c, t_float, X_one_hot, x_u8, prep, sparse_X, Y, 0, n));
     for (int l = 0; l < c.nl; ++l) GM_TRY(tower_layer(c, l, rowptr, colidx, nullptr, 0, n));
     GM_TRY(tower_output(c, out, out_row_begin, out_row_end));
     if (hcat_out) GM_HIP(hipMemcpyAsync(hcat_out, c.hcat, sizeof(float) * (size_t)(n * c.Hc), hipMemcpyDeviceToDevice, c.s));
@@ -194,9 +224,10 @@ extern "C" int gm_tower_forward(const gm_tower_dims* d, const float* const* P, i
 }
 
 extern "C" int gm_tower_stage(const gm_tower_dims* d, const float* const* P, int64_t n, int stage, int64_t row_begin,
-                              int64_t row_end, const float* t_float, const float* X_one_hot, const int32_t* Y,
-                              const int32_t* rowptr, const int32_t* colidx, const float* layer_src, float* layer_dst,
-                              float* out, void* workspace, size_t workspace_bytes, gm_stream_t stream) {
+                              int64_t row_end, const float* t_float, const float* X_one_hot, const uint8_t* x_u8,
+                              const float* prep, int sparse_X, const int32_t* Y, const int32_t* rowptr, const int32_t* colidx,
+                              const float* layer_src, float* layer_dst, float* out, void* workspace, size_t workspace_bytes,
+                              gm_stream_t stream) {
     TowerCtx c;
     if (int rc = tower_ctx(c, d, P, n, workspace, workspace_bytes, stream)) return rc;
     GM_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= n, "bad row range [%lld,%lld)", (long long)row_begin,
@@ -204,7 +235,7 @@ extern "C" int gm_tower_stage(const gm_tower_dims* d, const float* const* P, int
     GM_REQUIRE(stage >= -1 && stage <= c.nl, "stage %d out of range [-1,%d]", stage, c.nl);
     if (stage == -1) {
         GM_REQUIRE(t_float && Y, "null pointer");
-        GM_TRY(tower_input(c, t_float, X_one_hot, Y, row_begin, row_end));
+        GM_TRY(tower_input(c, t_float, X_one_hot, x_u8, prep, sparse_X, Y, row_begin, row_end));
     } else if (stage < c.nl) {
         GM_REQUIRE(d->is_mlp || (rowptr && colidx), "GNN tower needs a CSR adjacency");
         GM_TRY(tower_layer(c, stage, rowptr, colidx, layer_src, row_begin, row_end));

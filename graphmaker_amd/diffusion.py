@@ -121,6 +121,9 @@ class BaseModel(nn.Module):
         self.Y_marginal = Y_marginal
         self.E_marginal = E_marginal
         self._sample_calls = 0
+        # bag-of-words-like attributes (few ones per node): the towers' first layer walks the set attributes instead of
+        # running its GEMM (same bits either way, gm_onehot.hip); break-even is near 9% ones at the reference's hidden sizes
+        self._sparse_X = float(X_marginal[:, 1].float().mean()) < 0.06
         self._pair_ws = None
         self._prof = None          # None, or dict phase -> [(start_event, end_event)] (bench.py / profiling)
 
@@ -270,7 +273,7 @@ class BaseModel(nn.Module):
         return dev
 
     def _structure_step(self, pred_E, t_float, X_one_hot, Y32, bits_t, tab_E, seed, step, u=None, plan=None, group=None,
-                        reuse_X=False, after_csr=None, before_pair=None):
+                        reuse_X=False, after_csr=None, before_pair=None, x_u8=None):
         """get_E_t (model/diffusion.py:428-472): returns (A_t, symmetric bitmap of E_s).
         plan: parallel.ShardPlan for the one-process-per-GPU decomposition (None = single GPU).
         reuse_X: X_one_hot is the tensor of the previous call (ModelAsync's structure steps): mlp_in_X(X) is not recomputed.
@@ -283,12 +286,12 @@ class BaseModel(nn.Module):
         enc = pred_E.gnn_encoder
         with self.phase("tower_E"):
             if plan is None:
-                h = enc._run(t_float, X_one_hot, Y32, A_t, reuse_X=reuse_X)
+                h = enc._run(t_float, X_one_hot, Y32, A_t, reuse_X=reuse_X, x_u8=x_u8)
             else:
                 h_pad = self._buf("h_pad", (plan.world * plan.node_rows, enc._dims.out_size), torch.float32,
                                   X_one_hot.device)
                 enc._run_sharded(t_float, X_one_hot, Y32, A_t, plan, group, h_pad[:n], parallel.all_gather_node_rows,
-                                 reuse_X=reuse_X)
+                                 reuse_X=reuse_X, x_u8=x_u8)
         if plan is not None:
             with self.phase("allgather_h"):
                 h = parallel.all_gather_node_rows(plan, h_pad, group)[:n]
@@ -310,15 +313,15 @@ class BaseModel(nn.Module):
             bits_s = ops.symmetrize_upper(upper[:n], n)
         return A_t, bits_s
 
-    def _logits_fn(self, pred_X, t_float, x_onehot, Y32, A_t, plan, group):
+    def _logits_fn(self, pred_X, t_float, x_onehot, Y32, A_t, plan, group, x_u8=None):
         """rows -> (n, 2F) attribute logits valid on `rows` (all rows on a single GPU)."""
         if plan is None:
-            return lambda rows: pred_X._run(t_float, x_onehot, Y32, A_t)
+            return lambda rows: pred_X._run(t_float, x_onehot, Y32, A_t, x_u8=x_u8)
         n = self.num_nodes
 
         def sharded(rows):
             out = self._buf("logits", (n, pred_X._dims.out_size), torch.float32, x_onehot.device)
-            return pred_X._run_sharded(t_float, x_onehot, Y32, A_t, plan, group, out, parallel.all_gather_node_rows)
+            return pred_X._run_sharded(t_float, x_onehot, Y32, A_t, plan, group, out, parallel.all_gather_node_rows, x_u8=x_u8)
         return sharded
 
     def _attribute_draw(self, logits_fn, x, tab_X, seed, step, u=None, plan=None, group=None):
@@ -364,6 +367,7 @@ class ModelSync(BaseModel):
         self.graph_encoder = GNN(num_attrs_X=self.num_attrs_X, num_classes_X=self.num_classes_X,
                                  num_classes_Y=self.num_classes_Y, num_classes_E=self.num_classes_E,
                                  gnn_X_config=gnn_X_config, gnn_E_config=gnn_E_config)
+        self.graph_encoder.pred_X._sparse_X = self.graph_encoder.pred_E.gnn_encoder._sparse_X = self._sparse_X
 
     def step_tables(self, t):
         """Host tables of reverse step t (s = t-1): model/diffusion.py:852-858, 889-891."""
@@ -450,8 +454,8 @@ class ModelSync(BaseModel):
             wall.__enter__()
             side.wait_stream(cur)                                               # A_t (and the step's inputs) are ready
             with torch.cuda.stream(side):
-                res["x"], res["oh"] = self._attribute_draw(self._logits_fn(pred_X, t_float, x_onehot, Y32, A_t, None, None),
-                                                           x, tab_X, seed, t, u=uX)
+                res["x"], res["oh"] = self._attribute_draw(self._logits_fn(pred_X, t_float, x_onehot, Y32, A_t, None, None,
+                                                                           x_u8=x), x, tab_X, seed, t, u=uX)
 
         def join():
             cur.wait_stream(side)
@@ -460,7 +464,7 @@ class ModelSync(BaseModel):
                 v.record_stream(cur)
 
         _, bits_s = self._structure_step(self.graph_encoder.pred_E, t_float, x_onehot, Y32, bits_t, tab_E, seed, t, u=uE,
-                                         after_csr=attribute_branch, before_pair=join)
+                                         after_csr=attribute_branch, before_pair=join, x_u8=x)
         return res["x"], res["oh"], bits_s
 
     def _denoise_step_sharded(self, t, t_float, x, x_onehot, Y32, bits_t, tab_E, tab_X, seed, uE, uX, plan, group):
@@ -480,8 +484,8 @@ class ModelSync(BaseModel):
         x_pad = self._buf("x_pad", (plan.world * plan.node_rows, x.shape[1]), torch.uint8, dev)
         start = parallel.start_all_gather_node_rows
         with self.phase("towers"):
-            stages = [enc._sharded_stages(t_float, x_onehot, Y32, A_t, plan, group, h_pad[:n], start),
-                      pred_X._sharded_stages(t_float, x_onehot, Y32, A_t, plan, group, logits, start)]
+            stages = [enc._sharded_stages(t_float, x_onehot, Y32, A_t, plan, group, h_pad[:n], start, x_u8=x),
+                      pred_X._sharded_stages(t_float, x_onehot, Y32, A_t, plan, group, logits, start, x_u8=x)]
             while stages:
                 for g in list(stages):
                     try:
@@ -550,6 +554,7 @@ class ModelAsync(BaseModel):
         self.graph_encoder = GNNAsymm(num_attrs_X=self.num_attrs_X, num_classes_X=self.num_classes_X,
                                       num_classes_Y=self.num_classes_Y, num_classes_E=self.num_classes_E,
                                       mlp_X_config=mlp_X_config, gnn_E_config=gnn_E_config)
+        self.graph_encoder.pred_X._sparse_X = self.graph_encoder.pred_E.gnn_encoder._sparse_X = self._sparse_X
 
     def table_X(self, t):
         ns = self.noise_schedule_X
@@ -628,8 +633,8 @@ class ModelAsync(BaseModel):
         t_float = self._const(("tX", t, self.T_X), np.array([t / self.T_X], np.float32), dev)
         pred_X = self.graph_encoder.pred_X
         uX = uniforms.get(("X", t)) if uniforms else None
-        return self._attribute_draw(self._logits_fn(pred_X, t_float, x_onehot, Y32, None, plan, group), x, self.table_X(t),
-                                    seed, t, u=uX, plan=plan, group=group)
+        return self._attribute_draw(self._logits_fn(pred_X, t_float, x_onehot, Y32, None, plan, group, x_u8=x), x,
+                                    self.table_X(t), seed, t, u=uX, plan=plan, group=group)
 
     @torch.no_grad()
     def structure_step(self, t, x_onehot, Y32, bits_t, seed, uniforms=None, plan=None, group=None, reuse_X=False):

@@ -64,6 +64,10 @@ class _TowerBase(nn.Module):
         self._ptr_key = None
         self._ptr_arr = None
         self._ws = None
+        self._prep_buf, self._prep_key = None, None
+        # True: the first layer walks each node's set attributes instead of running the GEMM (same bits; pays when the
+        # attributes are sparse).  The diffusion models set it from the attribute marginals.
+        self._sparse_X = False
         # dropout masks are Philox(seed, call, element): the containers (GNN / GNNAsymm) give each of their towers its own
         # key, otherwise pred_X and pred_E.gnn_encoder (same hidden sizes in every reference config) would draw identical
         # masks step after step
@@ -91,6 +95,16 @@ class _TowerBase(nn.Module):
             self._ptr_key = key
         return self._ptr_arr
 
+    def _prep(self):
+        """B, D, D^T of the first layer (include/graphmaker_hip.h), recomputed when mlp_in_X.0 has been updated."""
+        w, b = self.mlp_in_X[0].weight, self.mlp_in_X[0].bias
+        key = (w.data_ptr(), w._version, b.data_ptr(), b._version)
+        if key != self._prep_key:
+            self._prep_buf = ops.tower_prepare(self._dims, self._param_ptrs(), w.device)
+            self._prep_key = key
+            self._hx0_rows = None                  # h_X^0 kept in the workspace came from the old weights
+        return self._prep_buf
+
     def _workspace(self, n, device):
         need = ops.tower_workspace_bytes(self._dims, n)
         if self._ws is None or self._ws.numel() < need or self._ws.device != device:
@@ -113,7 +127,8 @@ class _TowerBase(nn.Module):
         def mlp2(seq, x, relu_out):
             return ag.mlp2(x, seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias, relu_out)
 
-        h_X = mlp2(self.mlp_in_X, X_t_one_hot, True)
+        h_X = ag.mlp2(X_t_one_hot, self.mlp_in_X[0].weight, self.mlp_in_X[0].bias, self.mlp_in_X[2].weight,
+                      self.mlp_in_X[2].bias, True, onehot_sparse=self._sparse_X)      # first layer as in the fused call
         h_Y = ag.embedding(self.emb_Y.weight, Y32)
         h_t_exp = h_t.expand(n, -1)
         hX_list, hY_list = [h_X], [h_Y]
@@ -136,7 +151,7 @@ class _TowerBase(nn.Module):
         h_cat = torch.cat(hX_list + hY_list + [h_t_exp], dim=1)
         return mlp2(self.mlp_out, h_cat, False)
 
-    def _run(self, t_float, X_t_one_hot, Y_real, A_t, want_hcat=False, rows=None, out=None, reuse_X=False):
+    def _run(self, t_float, X_t_one_hot, Y_real, A_t, want_hcat=False, rows=None, out=None, reuse_X=False, x_u8=None):
         """reuse_X: the caller guarantees that X_t_one_hot, the parameters and the node count are those of the previous
         fused call of THIS tower, so mlp_in_X(X) is taken from the tower's workspace (ModelAsync's structure steps)."""
         if self._on_tape() and not want_hcat and rows is None and out is None:
@@ -148,13 +163,15 @@ class _TowerBase(nn.Module):
         Y32 = Y_real if Y_real.dtype == torch.int32 else Y_real.to(torch.int32)
         t = t_float.reshape(1).to(torch.float32)
         ws = self._workspace(n, X.device)
+        prep = self._prep()
         reuse = reuse_X and getattr(self, "_hx0_rows", None) == (n, None)
         self._hx0_rows = (n, None)
         return ops.tower_forward(self._dims, self._param_ptrs(), n, t, None if reuse else X, Y32.contiguous(), A_t, ws,
-                                 want_hcat=want_hcat, rows=rows, out=out)
+                                 want_hcat=want_hcat, rows=rows, out=out, prep=prep, x_u8=None if reuse else x_u8,
+                                 sparse_X=self._sparse_X)
 
 
-    def _run_sharded(self, t_float, X_t_one_hot, Y_real, A_t, plan, group, out, gather, reuse_X=False):
+    def _run_sharded(self, t_float, X_t_one_hot, Y_real, A_t, plan, group, out, gather, reuse_X=False, x_u8=None):
         """Row-sharded forward for the one-process-per-GPU decomposition: this rank computes node rows
         plan.node_range() of every stage; before each message-passing layer the [h_X | h_Y] rows of all ranks are
         replicated by `gather` (parallel.all_gather_node_rows).  Writes rows node_range() of `out` (n, out_size)."""
@@ -164,11 +181,11 @@ class _TowerBase(nn.Module):
 
             def wait(self):
                 pass
-        for _ in self._sharded_stages(t_float, X_t_one_hot, Y_real, A_t, plan, group, out, _Now, reuse_X=reuse_X):
+        for _ in self._sharded_stages(t_float, X_t_one_hot, Y_real, A_t, plan, group, out, _Now, reuse_X=reuse_X, x_u8=x_u8):
             pass
         return out
 
-    def _sharded_stages(self, t_float, X_t_one_hot, Y_real, A_t, plan, group, out, gather_start, reuse_X=False):
+    def _sharded_stages(self, t_float, X_t_one_hot, Y_real, A_t, plan, group, out, gather_start, reuse_X=False, x_u8=None):
         """_run_sharded as a generator: it yields right after each all-gather has been STARTED
         (gather_start(plan, buffer, group) -> handle with .wait(), parallel.start_all_gather_node_rows) and waits for it
         when resumed, so the caller can enqueue other kernels (the other tower's stage) under the transfer."""
@@ -178,9 +195,10 @@ class _TowerBase(nn.Module):
         t = t_float.reshape(1).to(torch.float32)
         dev = X.device
         d, ptrs, ws = self._dims, self._param_ptrs(), self._workspace(n, dev)
+        prep = self._prep()
         rows = plan.node_range()
         if reuse_X and getattr(self, "_hx0_rows", None) == (n, rows):
-            X = None                               # mlp_in_X(X) of these rows is still in the workspace
+            X = x_u8 = None                        # mlp_in_X(X) of these rows is still in the workspace
         self._hx0_rows = (n, rows)
         need_gather = not self._is_mlp and d.num_layers > 0
         width = d.hidden_X + d.hidden_Y
@@ -191,7 +209,8 @@ class _TowerBase(nn.Module):
                 self._gather_bufs = [torch.empty(key[:2], dtype=torch.float32, device=dev) for _ in range(2)]
                 self._gather_key = key
             bufs = self._gather_bufs
-        ops.tower_stage(d, ptrs, n, -1, rows, ws, t_float=t, X_one_hot=X, Y32=Y32, layer_dst=bufs[0])
+        ops.tower_stage(d, ptrs, n, -1, rows, ws, t_float=t, X_one_hot=X, Y32=Y32, layer_dst=bufs[0], prep=prep, x_u8=x_u8,
+                        sparse_X=self._sparse_X)
         for l in range(d.num_layers):
             src = None
             if need_gather:

@@ -159,6 +159,24 @@ def linear(A, W, bias=None, relu=False):
     return out
 
 
+def onehot_linear(x_u8, W, bias, relu=False, sparse=False):
+    """relu?(X_one_hot @ W^T + b) for the one-hot matrix of the binary attributes x_u8 (n, F); W is (H, 2F)."""
+    require(x_u8, torch.uint8, "x")
+    require(W, torch.float32, "W")
+    n, F = x_u8.shape
+    H = W.shape[0]
+    if W.shape[1] != 2 * F:
+        raise ValueError(f"onehot_linear: x is {tuple(x_u8.shape)}, W is {tuple(W.shape)}")
+    dev = x_u8.device
+    prep = torch.empty(L.load().gm_onehot_prep_floats(I64(F), I64(H)), dtype=torch.float32, device=dev)
+    L.call("gm_onehot_prepare", I64(F), I64(H), ptr(W), ptr(bias), ptr(prep), stream_ptr())
+    out = torch.empty((n, H), dtype=torch.float32, device=dev)
+    dense = None if sparse else torch.empty((n, (F + 3) // 4 * 4), dtype=torch.float32, device=dev)
+    L.call("gm_onehot_linear", I64(n), I64(F), I64(H), ptr(x_u8), ptr(prep), ptr(dense), ptr(out), I64(H), I32(int(relu)),
+           stream_ptr())
+    return out
+
+
 def layernorm_(X, gamma, beta, eps=1e-5):
     require(X, torch.float32, "X")
     M, N = X.shape
@@ -172,10 +190,28 @@ def tower_workspace_bytes(dims, n):
     return nbytes.value
 
 
-def tower_forward(dims, param_ptrs, n, t_float, X_one_hot, Y32, adj, workspace, out=None, want_hcat=False, rows=None):
-    """X_one_hot=None: reuse mlp_in_X(X) left in `workspace` by the previous call (same attributes, see the header)."""
+def tower_prepare(dims, param_ptrs, device):
+    """The weight-only part of a tower's first layer (gm_tower_prepare): B, D and D^T of include/graphmaker_hip.h."""
+    nfl = L.load().gm_tower_prep_floats(C.byref(dims))
+    if nfl <= 0:
+        raise ValueError("bad tower dims")
+    prep = torch.empty(nfl, dtype=torch.float32, device=device)
+    L.call("gm_tower_prepare", C.byref(dims), param_ptrs, ptr(prep), stream_ptr())
+    return prep
+
+
+def tower_forward(dims, param_ptrs, n, t_float, X_one_hot, Y32, adj, workspace, out=None, want_hcat=False, rows=None, *,
+                  prep, x_u8=None, sparse_X=False):
+    """X_one_hot=None and x_u8=None: reuse mlp_in_X(X) left in `workspace` by the previous call (same attributes, see the
+    header).  x_u8 (n, F) uint8 takes precedence over X_one_hot (n, 2F)."""
     require(t_float, torch.float32, "t_float")
     require(Y32, torch.int32, "Y")
+    require(prep, torch.float32, "prep")
+    if x_u8 is not None:
+        require(x_u8, torch.uint8, "x")
+        if x_u8.shape != (n, dims.in_X // 2):
+            raise ValueError(f"x is {tuple(x_u8.shape)}, expected {(n, dims.in_X // 2)}")
+        X_one_hot = None
     if X_one_hot is not None:
         require(X_one_hot, torch.float32, "X_t_one_hot")
         if X_one_hot.shape != (n, dims.in_X):
@@ -187,22 +223,24 @@ def tower_forward(dims, param_ptrs, n, t_float, X_one_hot, Y32, adj, workspace, 
     hcat = torch.empty((n, dims.hidden_cat), dtype=torch.float32, device=dev) if want_hcat else None
     rowptr = adj.rowptr if adj is not None else None
     colidx = adj.colidx if adj is not None else None
-    L.call("gm_tower_forward", C.byref(dims), param_ptrs, I64(n), ptr(t_float), ptr(X_one_hot), ptr(Y32), ptr(rowptr),
-           ptr(colidx), ptr(out), ptr(hcat), I64(rows[0] if rows else 0), I64(rows[1] if rows else n), ptr(workspace),
-           C.c_size_t(workspace.numel()), stream_ptr())
+    L.call("gm_tower_forward", C.byref(dims), param_ptrs, I64(n), ptr(t_float), ptr(X_one_hot), ptr(x_u8), ptr(prep),
+           I32(int(sparse_X)), ptr(Y32), ptr(rowptr), ptr(colidx), ptr(out), ptr(hcat), I64(rows[0] if rows else 0),
+           I64(rows[1] if rows else n), ptr(workspace), C.c_size_t(workspace.numel()), stream_ptr())
     return (out, hcat) if want_hcat else out
 
 
 def tower_stage(dims, param_ptrs, n, stage, rows, workspace, *, t_float=None, X_one_hot=None, Y32=None, adj=None,
-                layer_src=None, layer_dst=None, out=None):
+                layer_src=None, layer_dst=None, out=None, prep=None, x_u8=None, sparse_X=False):
     """One row-sharded stage of a tower (gm_tower_stage): -1 input projections, 0..L-1 layers, L output MLP."""
     rowptr = adj.rowptr if adj is not None else None
     colidx = adj.colidx if adj is not None else None
     if stage == -1 and Y32 is not None:
         check_index_range(Y32, dims.num_classes_Y, "Y")
+    if x_u8 is not None:
+        X_one_hot = None
     L.call("gm_tower_stage", C.byref(dims), param_ptrs, I64(n), I32(stage), I64(rows[0]), I64(rows[1]), ptr(t_float),
-           ptr(X_one_hot), ptr(Y32), ptr(rowptr), ptr(colidx), ptr(layer_src), ptr(layer_dst), ptr(out), ptr(workspace),
-           C.c_size_t(workspace.numel()), stream_ptr())
+           ptr(X_one_hot), ptr(x_u8), ptr(prep), I32(int(sparse_X)), ptr(Y32), ptr(rowptr), ptr(colidx), ptr(layer_src),
+           ptr(layer_dst), ptr(out), ptr(workspace), C.c_size_t(workspace.numel()), stream_ptr())
 
 
 def hadamard_gather(h, src, dst):

@@ -101,12 +101,28 @@ int gm_layernorm(int64_t M, int64_t N, float* X, int64_t ldx, const float* gamma
  * runs only on this range, which is how one tower is sharded over GPUs (pass 0, n for everything).
  * X_one_hot == NULL (here and in stage -1 of gm_tower_stage): the attributes are those of the previous call on this
  * workspace, so mlp_in_X(X) (model/gnn.py:154) is taken from the workspace instead of being recomputed -- the structure
- * steps of ModelAsync.sample condition on the final attributes (model/diffusion.py:1379-1401), only t and A_t change. */
+ * steps of ModelAsync.sample condition on the final attributes (model/diffusion.py:1379-1401), only t and A_t change.
+ * First layer (mlp_in_X.0, model/gnn.py:121-126,154).  X_t_one_hot is exactly one-hot with two classes per attribute
+ * (model/diffusion.py:232-235), so X W^T + b = B + sum_{f: x_f = 1} D[:, f] with D[o][f] = W[o][2f+1] - W[o][2f] and
+ * B[o] = (sum_f W[o][2f]) + b[o]: half the GEMM (K = F), or -- sparse_X != 0, for bag-of-words attributes with few ones -- a
+ * walk over each node's set attributes; both give the same bits.  `prep` holds B, D and D^T: gm_tower_prep_floats() floats,
+ * filled by gm_tower_prepare once per version of the weights.  The attributes come either as x_u8 (n, F) in {0,1} or as
+ * X_one_hot (n, 2F) (then they are recovered from it into the workspace); both NULL = reuse, as described above. */
 int gm_tower_workspace_bytes(const gm_tower_dims* dims, int64_t n, size_t* bytes);
+int64_t gm_tower_prep_floats(const gm_tower_dims* dims);
+int gm_tower_prepare(const gm_tower_dims* dims, const float* const* params, float* prep, gm_stream_t stream);
 int gm_tower_forward(const gm_tower_dims* dims, const float* const* params, int64_t n, const float* t_float,
-                     const float* X_one_hot, const int32_t* Y, const int32_t* rowptr, const int32_t* colidx,
-                     float* out, float* hcat_out, int64_t out_row_begin, int64_t out_row_end, void* workspace,
-                     size_t workspace_bytes, gm_stream_t stream);
+                     const float* X_one_hot, const uint8_t* x_u8, const float* prep, int sparse_X, const int32_t* Y,
+                     const int32_t* rowptr, const int32_t* colidx, float* out, float* hcat_out, int64_t out_row_begin,
+                     int64_t out_row_end, void* workspace, size_t workspace_bytes, gm_stream_t stream);
+/* The first layer on its own (what the towers call; also used by the training tape, model/diffusion.py:606-654).
+ * gm_onehot_prepare: prep (gm_onehot_prep_floats(F, H) floats) from W (H, 2F) row-major and b (H, may be NULL).
+ * gm_onehot_linear: out (n, H; ldo) = act(B + sum of the set attributes' columns of D); dense_ws = (n, roundup(F,4)) floats
+ * selects the GEMM form, NULL the sparse walk (needs H % 4 == 0, H <= 2048, F < 65536). */
+int64_t gm_onehot_prep_floats(int64_t F, int64_t H);
+int gm_onehot_prepare(int64_t F, int64_t H, const float* W, const float* b, float* prep, gm_stream_t stream);
+int gm_onehot_linear(int64_t n, int64_t F, int64_t H, const uint8_t* x, const float* prep, float* dense_ws, float* out,
+                     int64_t ldo, int relu, gm_stream_t stream);
 
 /* One stage of a tower for node rows [row_begin,row_end) -- the unit of the multi-GPU decomposition, in which every
  * stage is row-sharded and only the aggregation input crosses GPUs (same workspace for all stages of one forward):
@@ -118,9 +134,9 @@ int gm_tower_forward(const gm_tower_dims* dims, const float* const* params, int6
  * layer_dst: optional (n, hidden_X+hidden_Y) buffer; rows [row_begin,row_end) receive [h_X | h_Y] as written by this
  *            stage (stage -1 -> h^0, stage l -> h^(l+1)): the send side of the all-gather. */
 int gm_tower_stage(const gm_tower_dims* dims, const float* const* params, int64_t n, int stage, int64_t row_begin,
-                   int64_t row_end, const float* t_float, const float* X_one_hot, const int32_t* Y,
-                   const int32_t* rowptr, const int32_t* colidx, const float* layer_src, float* layer_dst, float* out,
-                   void* workspace, size_t workspace_bytes, gm_stream_t stream);
+                   int64_t row_end, const float* t_float, const float* X_one_hot, const uint8_t* x_u8, const float* prep,
+                   int sparse_X, const int32_t* Y, const int32_t* rowptr, const int32_t* colidx, const float* layer_src,
+                   float* layer_dst, float* out, void* workspace, size_t workspace_bytes, gm_stream_t stream);
 
 /* z[b] = h[src[b]] * h[dst[b]] for an explicit pair list: LinkPredictor.forward on a caller-chosen batch
  * (model/gnn.py:246); followed by two gm_linear calls it gives the (B,2) logits of model/gnn.py:248. */

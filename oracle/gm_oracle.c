@@ -469,7 +469,7 @@ void gmo_tower_forward(const gmo_tower_dims* d, const float* const* P, int64_t n
 
     /* mlp_in_X (:121-126,154) */
     float* tmpX = (float*)malloc(sizeof(float) * (size_t)(n * hX));
-    gmo_linear(n, hX, d->in_X, X_one_hot, d->in_X, P[4], d->in_X, P[5], tmpX, hX, 1);
+    gmo_onehot_linear(n, d->in_X / 2, hX, X_one_hot, P[4], P[5], tmpX, hX, 1);
     gmo_linear(n, hX, hX, tmpX, hX, P[6], hX, P[7], hcat + offX, Hc, 1);
     free(tmpX);
 
@@ -513,6 +513,47 @@ void gmo_tower_forward(const gmo_tower_dims* d, const float* const* P, int64_t n
     free(ht0);
     free(ht1);
     if (!hcat_dbg) free(hcat);
+}
+
+/* ------------------------------------------------------------------ first tower layer on one-hot attributes */
+/* relu(X_one_hot W^T + b) of mlp_in_X.0 (model/gnn.py:121-126,154) for a matrix that is exactly one-hot with two classes per
+ * attribute (X_t_one_hot[v][2f + x_vf] = 1, model/diffusion.py:232-235):
+ *     X W^T + b = B + sum_{f: x_vf = 1} D[:, f],   D[o][f] = W[o][2f+1] - W[o][2f],   B[o] = (sum_f W[o][2f]) + b[o].
+ * Orders: B[o] = (plain adds over ascending f, from 0) + b[o];  out = (plain adds of D[o][f] over ascending set f, from 0) + B[o].
+ * A chain fmaf(x_f, D[o][f], acc) over ALL f with x_f in {0,1} gives the same bits (a zero product leaves acc unchanged), which
+ * is how the dense form of the HIP library (an MFMA GEMM with K = F instead of 2F) and the sparse form (a walk over the set
+ * attributes) agree with each other and with this function. */
+void gmo_onehot_linear(int64_t n, int64_t F, int64_t H, const float* X_one_hot, const float* W, const float* b,
+                       float* out, int64_t ldo, int relu) {
+    float* Dt = (float*)malloc(sizeof(float) * (size_t)(F * H));
+    float* B = (float*)malloc(sizeof(float) * (size_t)H);
+    for (int64_t o = 0; o < H; ++o) {
+        float acc = 0.0f;
+        for (int64_t f = 0; f < F; ++f) {
+            acc = acc + W[o * 2 * F + 2 * f];
+            Dt[f * H + o] = W[o * 2 * F + 2 * f + 1] - W[o * 2 * F + 2 * f];
+        }
+        B[o] = acc + (b ? b[o] : 0.0f);
+    }
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int64_t v = 0; v < n; ++v) {
+        float* o_ = out + v * ldo;
+        for (int64_t o = 0; o < H; ++o) o_[o] = 0.0f;
+        for (int64_t f = 0; f < F; ++f) {
+            if (X_one_hot[v * 2 * F + 2 * f + 1] > X_one_hot[v * 2 * F + 2 * f]) {
+                const float* d = Dt + f * H;
+#pragma omp simd
+                for (int64_t o = 0; o < H; ++o) o_[o] = o_[o] + d[o];
+            }
+        }
+        for (int64_t o = 0; o < H; ++o) {
+            float r = o_[o] + B[o];
+            if (relu && !(r > 0.0f)) r = 0.0f;
+            o_[o] = r;
+        }
+    }
+    free(Dt);
+    free(B);
 }
 
 /* ------------------------------------------------------------------ structure denoiser */

@@ -136,6 +136,9 @@ void gmo_attr_posterior_sample(int64_t n, int64_t F, const float* logits /* (n,F
                                const uint8_t* x_t, const float* tab /* F*8 */, const float* u_or_null,
                                uint64_t seed, uint32_t step, uint8_t* x_s, float* post_dbg /* (n,F,2) */);
 void gmo_onehot_from_x(int64_t n, int64_t F, const uint8_t* x, float* oh);
+/* first tower layer on exactly-one-hot attributes, evaluated as base + corrections (see gm_oracle.c) */
+void gmo_onehot_linear(int64_t n, int64_t F, int64_t H, const float* X_one_hot, const float* W, const float* b,
+                       float* out, int64_t ldo, int relu);
 
 /* ---- whole trajectories (model/diffusion.py:797-905, 1295-1410) ----
  * Philox mode only (seed).  Outputs: x (n*F uint8), y (n int32), bits (n*wpr symmetric, zero diagonal).

@@ -273,6 +273,17 @@ def linear(A, W, bias=None, relu=False):
     return out
 
 
+def onehot_linear(X_one_hot, W, bias=None, relu=False):
+    X, W = f32(X_one_hot), f32(W)
+    n, F2 = X.shape
+    H = W.shape[0]
+    b = f32(bias) if bias is not None else None
+    out = np.empty((n, H), np.float32)
+    lib().gmo_onehot_linear(C.c_int64(n), C.c_int64(F2 // 2), C.c_int64(H), _p(X), _p(W), _p(b), _p(out), C.c_int64(H),
+                            C.c_int(int(relu)))
+    return out
+
+
 def layernorm(X, gamma, beta, eps=1e-5):
     X = f32(X).copy()
     M, N = X.shape

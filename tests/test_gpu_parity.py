@@ -160,6 +160,27 @@ def test_linear(dev, M, N, K, relu, bias):
     check_float(got, orc.linear(A, W, b, relu), 1e-5, f"linear {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("n,F,H,density", [(67, 11, 32, 0.2), (300, 767, 512, 0.011), (130, 1433, 512, 0.013), (200, 40, 1024, 0.1),
+                                               (33, 300, 48, 0.0), (50, 700, 512, 1.0), (257, 1030, 2048, 0.7), (64, 9, 20, 0.5)])
+def test_onehot_first_layer_dense_and_sparse_forms(dev, n, F, H, density):
+    """mlp_in_X.0 on one-hot attributes (model/gnn.py:121-126,154): the GEMM form (K = F) and the walk over the set attributes
+    give the oracle's bits (gmo_onehot_linear), from few ones per node to all ones (which overflows the walk's list and makes
+    it drain more than once); and the result stays within fp32 tolerance of the plain X_one_hot @ W^T + b."""
+    ops = _ops()
+    rs = np.random.RandomState(n + F + H)
+    x = (rs.uniform(size=(n, F)) < density).astype(np.uint8)
+    W = (rs.normal(size=(H, 2 * F)) / np.sqrt(2 * F)).astype(np.float32)
+    b = rs.normal(size=H).astype(np.float32)
+    oh = orc.onehot_from_x(x)
+    want = orc.onehot_linear(oh, W, b, relu=True)
+    np.testing.assert_allclose(want, np.maximum(oh.astype(np.float64) @ W.T.astype(np.float64) + b, 0), atol=2e-5, rtol=1e-5)
+    got_dense = ops.onehot_linear(t_(x, dev), t_(W, dev), t_(b, dev), relu=True, sparse=False)
+    check_float(got_dense, want, 1e-6, "one-hot first layer, GEMM form")
+    if H % 4 == 0:
+        got_sparse = ops.onehot_linear(t_(x, dev), t_(W, dev), t_(b, dev), relu=True, sparse=True)
+        check_float(got_sparse, want, 1e-6, "one-hot first layer, sparse walk")
+
+
 @pytest.mark.parametrize("M,N", [(5, 64), (67, 512), (33, 1024), (10, 100)])
 def test_layernorm(dev, M, N):
     ops = _ops()
@@ -483,7 +504,8 @@ def test_rank_shards_reproduce_single_gpu_step(dev, world):
         d, ptrs, ws = tower._dims, tower._param_ptrs(), tower._workspace(N, dev)
         bufs = [torch.full((N, d.hidden_X + d.hidden_Y), float("nan"), device=dev) for _ in range(2)]
         for pl in plans:
-            ops.tower_stage(d, ptrs, N, -1, pl.node_range(), ws, t_float=t_float, X_one_hot=X_oh, Y32=Y32, layer_dst=bufs[0])
+            ops.tower_stage(d, ptrs, N, -1, pl.node_range(), ws, t_float=t_float, X_one_hot=X_oh, Y32=Y32, layer_dst=bufs[0],
+                            prep=tower._prep(), sparse_X=tower._sparse_X)
         for l in range(d.num_layers):
             dst = bufs[(l + 1) & 1] if l + 1 < d.num_layers else None
             for pl in plans:
@@ -623,7 +645,8 @@ def test_eight_rank_shards_reproduce_single_gpu_step_at_amazon_computer_size(dev
         d, ptrs, ws = tower._dims, tower._param_ptrs(), tower._workspace(n, dev)
         bufs = [torch.full((n, d.hidden_X + d.hidden_Y), float("nan"), device=dev) for _ in range(2)]
         for pl in plans:
-            ops.tower_stage(d, ptrs, n, -1, pl.node_range(), ws, t_float=t_float, X_one_hot=X_oh, Y32=Y32, layer_dst=bufs[0])
+            ops.tower_stage(d, ptrs, n, -1, pl.node_range(), ws, t_float=t_float, X_one_hot=X_oh, Y32=Y32, layer_dst=bufs[0],
+                            prep=tower._prep(), sparse_X=tower._sparse_X)
         for l in range(d.num_layers):
             dst = bufs[(l + 1) & 1] if l + 1 < d.num_layers else None
             for pl in plans:
