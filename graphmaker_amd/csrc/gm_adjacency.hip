@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(1024) k_exclusive_scan(int64_t n, int32_t* __r
 // column indices in ascending order: one wave per row, lanes take words, in-wave prefix of popcounts
 __global__ void k_csr_fill(int64_t n, int64_t wpr, const uint32_t* __restrict__ bits, int upper_only,
                            const int32_t* __restrict__ rowptr, int64_t capacity, int32_t* __restrict__ colidx,
-                           int32_t* __restrict__ rows) {
+                           int32_t* __restrict__ rows, int32_t row_base = 0) {
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i >= n) return;
@@ -251,7 +251,7 @@ __global__ void k_csr_fill(int64_t n, int64_t wpr, const uint32_t* __restrict__ 
             word &= word - 1;
             if (pos < capacity) {
                 colidx[pos] = (int32_t)(w * 32 + b);
-                if (rows) rows[pos] = (int32_t)i;
+                if (rows) rows[pos] = (int32_t)i + row_base;
             }
             ++pos;
         }
@@ -264,6 +264,22 @@ __global__ void k_bitmap_from_edges(int64_t n, int64_t wpr, int64_t m, const int
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= m) return;
     const int64_t i = ei[e], j = ej[e];
+    if (i < 0 || j < 0 || i >= n || j >= n) return;
+    atomicOr(&bits[i * wpr + (j >> 5)], 1u << (j & 31));
+    atomicOr(&bits[j * wpr + (i >> 5)], 1u << (i & 31));
+}
+
+// every rank's segment of the gathered edge lists -> symmetric bitmap: segment s = [ei (cap) | ej (cap) | count | pad]
+__global__ void k_bitmap_from_edge_segments(int64_t n, int64_t wpr, int nseg, int64_t cap, int64_t stride,
+                                            const int32_t* __restrict__ edges, uint32_t* __restrict__ bits) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (int64_t)nseg * cap) return;
+    const int64_t s = g / cap, e = g - s * cap;
+    const int32_t* seg = edges + s * stride;
+    int64_t cnt = seg[2 * cap];
+    if (cnt > cap) cnt = cap;
+    if (e >= cnt) return;
+    const int64_t i = seg[e], j = seg[cap + e];
     if (i < 0 || j < 0 || i >= n || j >= n) return;
     atomicOr(&bits[i * wpr + (j >> 5)], 1u << (j & 31));
     atomicOr(&bits[j * wpr + (i >> 5)], 1u << (i & 31));
@@ -359,6 +375,57 @@ extern "C" int gm_bitmap_from_upper_edges(int64_t n, int64_t wpr, int64_t m, con
     GM_HIP(hipMemsetAsync(bits, 0, sizeof(uint32_t) * (size_t)(n * wpr), as_stream(stream)));
     if (m == 0) return GM_OK;
     hipLaunchKernelGGL(k_bitmap_from_edges, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, as_stream(stream), n, wpr, m, ei, ej, bits);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+// ---- multi-GPU: the sampled edges of a rank's rows as a compact list, and the bitmap back from every rank's list
+extern "C" int gm_upper_edges_ranges(int64_t n, int64_t wpr, const uint32_t* upper, int nranges, const int64_t* row_ranges,
+                                     int64_t capacity, int32_t* rowptr_ws, int32_t* ei, int32_t* ej, int32_t* count,
+                                     int32_t* overflow, gm_stream_t stream) {
+    if (int rc = check_bitmap_args(n, wpr)) return rc;
+    GM_REQUIRE(upper && rowptr_ws && ei && ej && count && overflow && row_ranges, "null pointer");
+    GM_REQUIRE(nranges >= 1 && nranges <= 4, "between 1 and 4 row ranges");
+    GM_REQUIRE(capacity > 0 && capacity < (1ll << 31), "bad capacity");
+    hipStream_t s = as_stream(stream);
+    int64_t total = 0;
+    for (int r = 0; r < nranges; ++r) {
+        const int64_t b = row_ranges[2 * r], e = row_ranges[2 * r + 1];
+        GM_REQUIRE(0 <= b && b <= e, "bad row range [%lld,%lld)", (long long)b, (long long)e);
+        if (e == b) continue;
+        // `upper` holds only bits j > i in the words the pair kernel writes and zeros elsewhere: plain row degrees
+        hipLaunchKernelGGL(k_row_degree, dim3((unsigned)((e - b + 3) / 4)), dim3(256), 0, s, e - b, wpr, upper + b * wpr, 0,
+                           rowptr_ws + total);
+        GM_LAUNCH_CHECK();
+        total += e - b;
+    }
+    if (total == 0) {
+        GM_HIP(hipMemsetAsync(count, 0, sizeof(int32_t), s));
+        return GM_OK;
+    }
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, total, rowptr_ws, capacity, overflow);
+    GM_LAUNCH_CHECK();
+    GM_HIP(hipMemcpyAsync(count, rowptr_ws + total, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    int64_t off = 0;
+    for (int r = 0; r < nranges; ++r) {
+        const int64_t b = row_ranges[2 * r], e = row_ranges[2 * r + 1];
+        if (e == b) continue;
+        hipLaunchKernelGGL(k_csr_fill, dim3((unsigned)((e - b + 3) / 4)), dim3(256), 0, s, e - b, wpr, upper + b * wpr, 0,
+                           rowptr_ws + off, capacity, ej, ei, (int32_t)b);
+        GM_LAUNCH_CHECK();
+        off += e - b;
+    }
+    return GM_OK;
+}
+
+extern "C" int gm_bitmap_from_edge_segments(int64_t n, int64_t wpr, int nseg, int64_t cap, int64_t stride,
+                                            const int32_t* edges, uint32_t* bits, gm_stream_t stream) {
+    if (int rc = check_bitmap_args(n, wpr)) return rc;
+    GM_REQUIRE(nseg > 0 && cap > 0 && stride > 2 * cap && edges && bits, "bad arguments");
+    GM_REQUIRE((int64_t)nseg * cap < (1ll << 38), "edge buffer too large");
+    GM_HIP(hipMemsetAsync(bits, 0, sizeof(uint32_t) * (size_t)(n * wpr), as_stream(stream)));
+    hipLaunchKernelGGL(k_bitmap_from_edge_segments, dim3((unsigned)(((int64_t)nseg * cap + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), n, wpr, nseg, cap, stride, edges, bits);
     GM_LAUNCH_CHECK();
     return GM_OK;
 }

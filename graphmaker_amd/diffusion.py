@@ -150,13 +150,30 @@ class BaseModel(nn.Module):
     def phase(self, name):
         return BaseModel._Phase(self, name)
 
-    def _buf(self, name, shape, dtype, device):
-        """Step-persistent scratch tensors of the sharded path (buffers that collectives touch are kept, not re-made)."""
+    def _buf(self, name, shape, dtype, device, zero=False):
+        """Step-persistent scratch tensors (buffers that collectives touch are kept, not re-made).  zero: cleared when it is
+        first made, never again."""
         cache = self.__dict__.setdefault("_bufs", {})
         key = (name, tuple(shape), dtype, device)
         if key not in cache:
-            cache[key] = torch.empty(shape, dtype=dtype, device=device)
+            cache[key] = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=device)
         return cache[key]
+
+    def _exchange_edges(self, plan, upper, group):
+        """The sampled edges of this rank's pair chunks -> compact sorted list -> one all-gather -> the symmetric bitmap of
+        E_s on every rank (model/diffusion.py:421-424 across ranks; parallel.py)."""
+        n, dev = self.num_nodes, upper.device
+        cap = parallel.edge_segment_capacity(plan, self.transition.E_marginal_host[1])
+        seg = self._buf("edge_seg", (2 * cap + parallel.SEG_HEADER,), torch.int32, dev, zero=True)
+        recv = self._buf("edge_recv", (plan.world, 2 * cap + parallel.SEG_HEADER), torch.int32, dev, zero=True)
+        rowptr_ws = self._buf("edge_rowptr", (2 * plan.chunk_rows + 1,), torch.int32, dev)
+        ovf = self._buf("edge_overflow", (1,), torch.int32, dev, zero=True)
+        with self.phase("edges_pack"):
+            ops.upper_edges_of_rows(upper, n, plan.pair_chunks(), seg, cap, rowptr_ws, ovf)
+        with self.phase("allgather_E"):
+            parallel.gather_edge_segments(plan, seg, recv, group)
+        with self.phase("symmetrize"):
+            return ops.bitmap_from_edge_segments(n, recv, cap)
 
     def _const(self, key, host_array, device):
         """Small per-step constants (time embedding input, posterior tables) uploaded once per (key, device) instead of
@@ -280,7 +297,8 @@ class BaseModel(nn.Module):
         after_csr(A_t) / before_pair(): hooks of the Sync step, which runs its attribute branch beside the edge encoder."""
         n = self.num_nodes
         with self.phase("csr"):      # built into the model's workspace: no host read of the edge count in a step
-            A_t = ops.adjacency_from_bitmap(bits_t, n, workspace=self._csr_ws(bits_t.device))
+            A_t = ops.adjacency_from_bitmap(bits_t, n, workspace=self._csr_ws(bits_t.device),
+                                            rows=None if plan is None else plan.node_range())
         if after_csr is not None:
             after_csr(A_t)
         enc = pred_E.gnn_encoder
@@ -299,16 +317,16 @@ class BaseModel(nn.Module):
             self._pair_ws = ops.pair_workspace(h.device)
         W1, b1, W2, b2 = pred_E.pair_params()
         ranges = [(0, n)] if plan is None else plan.pair_chunks()
-        upper = torch.zeros((n if plan is None else plan.padded_pair_rows, bits_t.shape[1]), dtype=torch.int32,
-                            device=h.device)
+        # zeroed once: the pair kernel rewrites every word it owns on each call and the others stay zero
+        upper = self._buf("upper", (n if plan is None else plan.padded_pair_rows, bits_t.shape[1]), torch.int32, h.device,
+                          zero=True)
         if before_pair is not None:
             before_pair()
         with self.phase("pair"):      # a rank's two folded chunks go into ONE launch (shared tile queue)
             ops.pair_score_sample(h, W1, b1, W2, b2, bits_t, tab_E, seed=seed, step=step, u=u, row_ranges=ranges,
                                   out_upper=upper, workspace=self._pair_ws)
         if plan is not None:
-            with self.phase("allgather_E"):
-                parallel.gather_upper_rows(plan, upper, group)
+            return A_t, self._exchange_edges(plan, upper, group)
         with self.phase("symmetrize"):
             bits_s = ops.symmetrize_upper(upper[:n], n)
         return A_t, bits_s
@@ -351,6 +369,12 @@ class BaseModel(nn.Module):
             self._csr_workspace.check()                                     # the one host read of a trajectory
         if self._pair_ws is not None:
             ops.check_pair_workspace(self._pair_ws)
+        for key, buf in self.__dict__.get("_bufs", {}).items():
+            if key[0] == "edge_overflow" and int(buf.item()):
+                buf.zero_()
+                raise RuntimeError("a rank sampled more edges than its exchange segment holds (parallel.edge_segment_capacity: "
+                                   "4x the edge marginal's share): the sample is invalid; the model's E_marginal does not "
+                                   "describe the graphs it generates")
         X = torch.transpose(x_onehot.reshape(n, Fa, -1), 0, 1)             # model/diffusion.py:899-901
         Y_one_hot = F.one_hot(Y32.long(), num_classes=self.num_classes_Y).float()
         if dense:
@@ -477,8 +501,8 @@ class ModelSync(BaseModel):
         n, dev = self.num_nodes, x.device
         ge = self.graph_encoder
         enc, pred_X = ge.pred_E.gnn_encoder, ge.pred_X
-        with self.phase("csr"):
-            A_t = ops.adjacency_from_bitmap(bits_t, n, workspace=self._csr_ws(dev))
+        with self.phase("csr"):      # only the rows this rank aggregates (its node block)
+            A_t = ops.adjacency_from_bitmap(bits_t, n, workspace=self._csr_ws(dev), rows=plan.node_range())
         h_pad = self._buf("h_pad", (plan.world * plan.node_rows, enc._dims.out_size), torch.float32, dev)
         logits = self._buf("logits", (n, pred_X._dims.out_size), torch.float32, dev)
         x_pad = self._buf("x_pad", (plan.world * plan.node_rows, x.shape[1]), torch.uint8, dev)
@@ -503,14 +527,11 @@ class ModelSync(BaseModel):
         if self._pair_ws is None or self._pair_ws.device != dev:
             self._pair_ws = ops.pair_workspace(dev)
         W1, b1, W2, b2 = ge.pred_E.pair_params()
-        upper = torch.zeros((plan.padded_pair_rows, bits_t.shape[1]), dtype=torch.int32, device=dev)
+        upper = self._buf("upper", (plan.padded_pair_rows, bits_t.shape[1]), torch.int32, dev, zero=True)
         with self.phase("pair"):
             ops.pair_score_sample(h, W1, b1, W2, b2, bits_t, tab_E, seed=seed, step=t, u=uE,
                                   row_ranges=plan.pair_chunks(), out_upper=upper, workspace=self._pair_ws)
-        with self.phase("allgather_E"):
-            parallel.gather_upper_rows(plan, upper, group)
-        with self.phase("symmetrize"):
-            bits_s = ops.symmetrize_upper(upper[:n], n)
+        bits_s = self._exchange_edges(plan, upper, group)
         with self.phase("allgather_X"):
             x_on_wire.wait()
             x_s = x_pad[:n].clone()                                  # x_pad is reused by the next step

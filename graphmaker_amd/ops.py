@@ -112,8 +112,21 @@ class CsrWorkspace:
                                "truncated and the sample is invalid (graphs this dense need the exact-size CSR path)")
 
 
-def adjacency_from_bitmap(bits, n, workspace=None):
-    """get_adj on the library's bitmap state.  workspace: a CsrWorkspace -> no host synchronisation (the step path)."""
+def adjacency_from_bitmap(bits, n, workspace=None, rows=None):
+    """get_adj on the library's bitmap state.  workspace: a CsrWorkspace -> no host synchronisation (the step path).
+    rows=(r0, r1) (with a workspace): only those rows of the adjacency are built -- rowptr[r0..r1] counts from 0 at r0 and
+    colidx holds their neighbours: what a rank of the multi-GPU step aggregates (its node block); other rows are undefined."""
+    if rows is not None and workspace is not None:
+        r0, r1 = rows
+        require(bits, torch.int32, "bits")
+        wpr = bits.shape[1]
+        rowptr = torch.empty(n + 1, dtype=torch.int32, device=bits.device)
+        if r1 > r0:
+            L.call("gm_csr_rowptr_capped", I64(r1 - r0), I64(wpr), ptr(bits[r0:r1]), I32(0), I64(workspace.capacity),
+                   ptr(rowptr[r0:r1 + 1]), ptr(workspace.overflow), stream_ptr())
+            L.call("gm_csr_fill", I64(r1 - r0), I64(wpr), ptr(bits[r0:r1]), I32(0), ptr(rowptr[r0:r1 + 1]),
+                   I64(workspace.capacity), ptr(workspace.colidx), None, stream_ptr())
+        return Adjacency(n, bits, rowptr, workspace.colidx, nnz=-1)
     if workspace is None:
         rowptr, colidx = csr_from_bitmap(bits, n)
         return Adjacency(n, bits, rowptr, colidx, nnz=int(colidx.numel()))
@@ -125,6 +138,28 @@ def adjacency_from_bitmap(bits, n, workspace=None):
     L.call("gm_csr_fill", I64(n), I64(wpr), ptr(bits), I32(0), ptr(rowptr), I64(workspace.capacity), ptr(workspace.colidx),
            None, stream_ptr())
     return Adjacency(n, bits, rowptr, workspace.colidx)
+
+
+def upper_edges_of_rows(upper, n, row_ranges, segment, cap, rowptr_ws, overflow):
+    """gm_upper_edges_ranges into a segment [ei (cap) | ej (cap) | count | pad] (int32, 2*cap + 16 entries): the sampled
+    edges (i<j) of `row_ranges` of the upper-triangle bitmap, sorted; count and an overflow flag stay on the device."""
+    require(upper, torch.int32, "upper")
+    require(segment, torch.int32, "segment")
+    flat = [int(v) for be in row_ranges for v in be]
+    ranges_host = (C.c_int64 * len(flat))(*flat)
+    L.call("gm_upper_edges_ranges", I64(n), I64(upper.shape[1]), ptr(upper), I32(len(flat) // 2), ranges_host, I64(cap),
+           ptr(rowptr_ws), ptr(segment), ptr(segment[cap:]), ptr(segment[2 * cap:]), ptr(overflow), stream_ptr())
+    return segment
+
+
+def bitmap_from_edge_segments(n, segments, cap, out=None):
+    """The symmetric bitmap of the edges held in `segments` (nseg, 2*cap + 16) int32 (upper_edges_of_rows layout)."""
+    require(segments, torch.int32, "segments")
+    wpr = words_per_row(n)
+    bits = out if out is not None else torch.empty((n, wpr), dtype=torch.int32, device=segments.device)
+    L.call("gm_bitmap_from_edge_segments", I64(n), I64(wpr), I32(segments.shape[0]), I64(cap), I64(segments.shape[1]),
+           ptr(segments), ptr(bits), stream_ptr())
+    return bits
 
 
 def bitmap_from_upper_edges(n, ei, ej):

@@ -78,6 +78,22 @@ int gm_csr_fill(int64_t n, int64_t wpr, const uint32_t* bits, int upper_only, co
 int gm_bitmap_from_upper_edges(int64_t n, int64_t wpr, int64_t m, const int32_t* ei, const int32_t* ej,
                                uint32_t* bits, gm_stream_t stream);
 
+/* Multi-GPU exchange of the sampled edges ("the sampled edge lists are gathered back": E_t[dst,src] = E_t[src,dst] = draw,
+ * model/diffusion.py:421-424, done across ranks).
+ * gm_upper_edges_ranges: the edges (i<j) of up to 4 row ranges (HOST array [b0,e0,b1,e1,...], a rank's pair chunks) of the
+ *   upper-triangle bitmap the pair kernel wrote, as a compact list sorted by (i, j): ei[k], ej[k] for k < *count (device
+ *   int32, clamped to `capacity`); rowptr_ws: scratch of R+1 entries, R = total number of rows in the ranges.  At most
+ *   `capacity` edges are written; *overflow (device, sticky) is OR-ed with 1 when there were more.  The rows of `upper` must
+ *   hold zeros in the words the pair kernel does not write (allocate it zeroed once; the kernel rewrites its words on every
+ *   call).
+ * gm_bitmap_from_edge_segments: the symmetric bitmap of E_s from every rank's list after ONE equal-sized all-gather of
+ *   segments [ei (cap) | ej (cap) | count | padding] of `stride` int32 each (stride > 2*cap). */
+int gm_upper_edges_ranges(int64_t n, int64_t wpr, const uint32_t* upper, int nranges, const int64_t* row_ranges,
+                          int64_t capacity, int32_t* rowptr_ws, int32_t* ei, int32_t* ej, int32_t* count, int32_t* overflow,
+                          gm_stream_t stream);
+int gm_bitmap_from_edge_segments(int64_t n, int64_t wpr, int nseg, int64_t cap, int64_t stride, const int32_t* edges,
+                                 uint32_t* bits, gm_stream_t stream);
+
 /* ---- message passing: A @ H with A = D^-1 A (model/gnn.py:60-61, model/diffusion.py:255-256) ---- */
 int gm_spmm_mean(int64_t n, const int32_t* rowptr, const int32_t* colidx, const float* H, int64_t ldh, int64_t d,
                  float* out, int64_t ldo, gm_stream_t stream);

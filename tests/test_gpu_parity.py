@@ -408,6 +408,59 @@ def test_pair_kernel_large_against_oracle_rows_and_sharding(dev):
     assert torch.equal(dense, dense.T) and int(dense.diagonal().sum()) == 0
 
 
+@pytest.mark.parametrize("n,density", [(67, 0.3), (777, 0.02), (2500, 0.004), (130, 0.0)])
+def test_edge_list_exchange_kernels(dev, n, density):
+    """The multi-GPU exchange of the sampled edges: every rank's rows of the upper-triangle bitmap -> sorted (i<j) edge
+    list in a segment [ei | ej | count] (gm_upper_edges_ranges), all segments -> the symmetric bitmap
+    (gm_bitmap_from_edge_segments).  Bit-exact against the oracle; a segment that is too small is truncated in bounds and
+    raises its flag; a partial-row adjacency equals the rows of the whole one."""
+    from graphmaker_amd.parallel import SEG_HEADER, ShardPlan
+    ops = _ops()
+    d, sym_bits = random_sym_bits(n, density, n + 1)
+    upper_np = orc.bitmap_from_dense(np.triu(d, 1))
+    ei, ej = orc.upper_edges_from_bitmap(sym_bits, n)
+    world = 3
+    plans = [ShardPlan.make(n, world, r) for r in range(world)]
+    cap = max(len(ei), 1) + 5
+    recv = torch.zeros((world, 2 * cap + SEG_HEADER), dtype=torch.int32, device=dev)
+    ovf = torch.zeros(1, dtype=torch.int32, device=dev)
+    rowptr_ws = torch.empty(2 * plans[0].chunk_rows + 1, dtype=torch.int32, device=dev)
+    upper = torch.zeros((plans[0].padded_pair_rows, upper_np.shape[1]), dtype=torch.int32, device=dev)
+    upper[:n] = bits_t(upper_np, dev)
+    got_i, got_j = [], []
+    for r, pl in enumerate(plans):
+        ops.upper_edges_of_rows(upper, n, pl.pair_chunks(), recv[r], cap, rowptr_ws, ovf)
+        c = int(recv[r, 2 * cap])
+        seg_i, seg_j = recv[r, :c].cpu().numpy(), recv[r, cap:cap + c].cpu().numpy()
+        rows = np.concatenate([np.arange(b, e) for b, e in pl.pair_chunks()])
+        keep = np.isin(ei, rows)
+        np.testing.assert_array_equal(seg_i, ei[keep])                  # sorted by (i, j), exactly this rank's rows
+        np.testing.assert_array_equal(seg_j, ej[keep])
+        got_i.append(seg_i)
+        got_j.append(seg_j)
+    assert int(ovf) == 0 and sum(len(a) for a in got_i) == len(ei)
+    back = ops.bitmap_from_edge_segments(n, recv, cap)
+    np.testing.assert_array_equal(bits_np(back), sym_bits)
+    if len(ei) > 8:                                                     # a segment that is too small
+        small = torch.full((2 * 4 + SEG_HEADER + 8,), -7, dtype=torch.int32, device=dev)
+        ops.upper_edges_of_rows(upper, n, [(0, n)], small, 4, torch.empty(n + 1, dtype=torch.int32, device=dev), ovf)
+        assert int(ovf) == 1 and int(small[8]) == 4
+        np.testing.assert_array_equal(small[:4].cpu().numpy(), ei[:4])
+        np.testing.assert_array_equal(small[4:8].cpu().numpy(), ej[:4])
+        assert bool((small[9:] == -7).all())
+    # partial-row adjacency (what a rank builds for its node block)
+    b = bits_t(sym_bits, dev)
+    full = ops.adjacency_from_bitmap(b, n)
+    ws = ops.CsrWorkspace(n, dev)
+    for pl in plans:
+        r0, r1 = pl.node_range()
+        part = ops.adjacency_from_bitmap(b, n, workspace=ws, rows=(r0, r1))
+        rp, frp = part.rowptr[r0:r1 + 1].cpu().numpy(), full.rowptr[r0:r1 + 1].cpu().numpy()
+        np.testing.assert_array_equal(rp, frp - frp[0])
+        np.testing.assert_array_equal(part.colidx[:rp[-1]].cpu().numpy(), full.colidx[frp[0]:frp[-1]].cpu().numpy())
+    ws.check()
+
+
 def test_capped_csr_matches_exact_and_flags_overflow(dev):
     """The step-local adjacency (no host read of the edge count) equals get_adj's CSR; a too-small buffer is truncated
     in bounds and reported."""

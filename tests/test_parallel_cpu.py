@@ -27,7 +27,8 @@ def _worker(rank, world, port, name, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from graphmaker_amd.parallel import ShardPlan, all_gather_node_rows, gather_upper_rows
+        from graphmaker_amd.parallel import (SEG_HEADER, ShardPlan, all_gather_node_rows, edge_segment_capacity,
+                                             gather_edge_segments)
         orc.set_threads(2)
         cfg = gu.CASES[name]
         g = gu.load_golden(name)
@@ -56,18 +57,30 @@ def _worker(rank, world, port, name, q):
             h = all_gather_node_rows(plan, h_pad)[:N].numpy()
         ok_h = np.array_equal(h, h_full)
 
-        # 2) pair matrix: this rank scores its two folded row chunks, then the rows are gathered
-        # (padded to whole chunks: pack / unpack are one kernel each; world 3 also takes the row-range fallback)
-        upper = torch.zeros((plan.padded_pair_rows if world == 2 else N, bits.shape[1]), dtype=torch.int32)
+        # 2) pair matrix: this rank scores its two folded row chunks, turns them into its sorted edge list (what
+        # gm_upper_edges_ranges does on the GPU) and the lists are gathered with one equal-sized all-gather of segments
+        # [ei | ej | count]; every rank rebuilds the symmetric bitmap (gm_bitmap_from_edge_segments)
+        cap = edge_segment_capacity(plan, cfg["density"])
+        assert cap == edge_segment_capacity(ShardPlan.make(N, world, (rank + 1) % world), cfg["density"])   # same on every rank
+        mine = np.zeros((N, bits.shape[1]), np.uint32)
         for r0, r1 in plan.pair_chunks():
             if r1 > r0:
                 part = orc.pair_score_sample(N, h, pair, bits, tab, seed=seed, step=t, row_begin=r0, row_end=r1)
-                upper[r0:r1] = torch.from_numpy(part[r0:r1].view(np.int32))
-        gather_upper_rows(plan, upper)
-        upper = upper[:N].contiguous()
-        sym = orc.symmetrize_upper(upper.numpy().view(np.uint32), N)
+                mine[r0:r1] = part[r0:r1]
+        ei, ej = orc.upper_edges_from_bitmap(orc.symmetrize_upper(mine, N), N)
+        assert len(ei) <= cap
+        seg = torch.zeros(2 * cap + SEG_HEADER, dtype=torch.int32)
+        seg[:len(ei)] = torch.from_numpy(ei)
+        seg[cap:cap + len(ej)] = torch.from_numpy(ej)
+        seg[2 * cap] = len(ei)
+        recv = torch.zeros((world, 2 * cap + SEG_HEADER), dtype=torch.int32)
+        gather_edge_segments(plan, seg, recv)
+        cnt = recv[:, 2 * cap].numpy()
+        all_i = np.concatenate([recv[r, :cnt[r]].numpy() for r in range(world)])
+        all_j = np.concatenate([recv[r, cap:cap + cnt[r]].numpy() for r in range(world)])
+        sym = orc.bitmap_from_upper_edges(N, all_i, all_j)
         want = orc.symmetrize_upper(orc.pair_score_sample(N, h_full, pair, bits, tab, seed=seed, step=t), N)
-        ok_e = np.array_equal(sym, want)
+        ok_e = np.array_equal(sym, want) and int(cnt.sum()) == len(orc.upper_edges_from_bitmap(want, N)[0])
 
         # 3) attributes: uint8 node-row shards
         x_full = g[f"x{t}_X_out"]
