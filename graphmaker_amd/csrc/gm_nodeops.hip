@@ -7,154 +7,226 @@
 namespace gm {
 
 // ---------------------------------------------------------------- SpMM (mean aggregation)
-// A group of TPR consecutive threads owns one output row; each thread keeps CH float4 column chunks
-// (chunk c = t + k*TPR, so one neighbour row is read as contiguous 16-byte pieces across the group) and walks the
-// row's neighbours in ascending order, acc = fmaf(H[j], 1/deg, acc) -- the order the oracle uses.
-// Neighbour ids are read 4 at a time so 4 independent row gathers are in flight per thread.
-// TRANSPOSED = true is the backward of the same operator for a symmetric adjacency: the weight of neighbour j is
-// 1/deg(j) instead of 1/deg(i)  ((D^-1 A)^T G, model/gnn.py:60-61 under autograd).
-template <int CH, bool TRANSPOSED = false>
+// out[i] = sum_{j in N(i)} w * H[j], w = 1/deg(i) (TRANSPOSED: 1/deg(j), the backward for a symmetric adjacency:
+// (D^-1 A)^T G, model/gnn.py:60-61 under autograd).
+//
+// Arithmetic (oracle gmo_spmm_mean): a row's neighbours, ascending, are cut into segments of SEG = 64; a segment is one
+// fmaf chain from 0; the row is the segment sums added in ascending segment order.  The cut makes the unit of work a
+// (row, segment) ITEM of at most 64 neighbours, whatever the degree distribution: a hub row of 3000 neighbours becomes 47
+// items that different lane groups run side by side, instead of one lane group walking it alone.
+//
+// Layout of a launch: the dense operand is cut into column slabs of 8 float4 chunks (128 B per row).  A workgroup (256
+// threads = 32 groups of 8 lanes, one chunk per lane) owns 32 consecutive rows of one slab.  Thread 0 lists the block's items
+// in LDS; the groups pull items from an LDS counter; for an item the 8 lanes read its <= 64 column indices from global memory
+// in one coalesced pass into the group's LDS slot, then walk them 8 at a time: eight 128-byte row pieces in flight per group,
+// eight fmaf in order.  Single-segment rows store straight to the output; the segment sums of longer rows meet in LDS and
+// are added in order after a barrier.
+// Slabs and XCDs: workgroups are dealt round-robin to the 8 XCDs, and a slab (n rows x 128 B <= 2.5 MB up to 20480 rows)
+// fits an XCD's 4 MB L2, so all gathers of a slab are issued from the XCD(s) that hold it after first touch -- the operand
+// is fetched across the L2 boundary about once instead of once per XCD.  With r < 8 slabs in a (last) round, XCD x takes slab
+// x % r and the rows are dealt over the XCDs that share a slab.  A wrong guess about placement costs speed only.
+constexpr int SP_SEG = 64;          // neighbours per segment (oracle: GMO_SPMM_SEG)
+constexpr int SP_RB = 32;           // rows per workgroup
+constexpr int SP_PARTS = 96;        // segment sums a workgroup can hold in LDS for its multi-segment rows (128-byte slabs)
+constexpr int SP_PARTS_WIDE = 16;   // ... with 2 KB slabs (each sum is 16x larger)
+constexpr int SP_SERIAL = 0xFFFF;   // item that walks all segments of its row itself (LDS slots exhausted)
+
+struct SpmmSched {
+    int64_t rowgroups;              // ceil(n / SP_RB)
+    int full_rounds;                // rounds of 8 slabs
+    int rem;                        // slabs in the last, partial round (0..7)
+    int64_t blocks_full;            // workgroups per full round = 8 * rowgroups
+    int64_t k_rem;                  // workgroups per XCD in the partial round
+};
+
+// TPR lanes per group and CH float4 chunks per lane: a slab is TPR * CH chunks wide.  <8, 1> is the 128-byte slab described
+// above; <64, 2> (one wave per item, 2 KB of a row per gather) is for operands far larger than the L2s (n > 20480), whose
+// gathers come from the Infinity Cache or HBM and want long contiguous pieces instead of XCD affinity.
+template <bool TRANSPOSED, int TPR, int CH>
 __global__ void __launch_bounds__(256)
-k_spmm_mean(int64_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
-            const float* __restrict__ H, int64_t ldh, int nchunks, int tpr, float* __restrict__ out, int64_t ldo) {
-    const int rows_per_block = 256 / tpr;
-    const int r = threadIdx.x / tpr;
-    const int t = threadIdx.x % tpr;
-    const int64_t i = (int64_t)blockIdx.x * rows_per_block + r;
-    if (r >= rows_per_block || i >= n) return;
-    const int b = rowptr[i], e = rowptr[i + 1];
-    float4 acc[CH];
+k_spmm_seg(int64_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, const float* __restrict__ H,
+           int64_t ldh, int nchunks, float* __restrict__ out, int64_t ldo, const SpmmSched sc) {
+    constexpr int NG = 256 / TPR;                       // groups per workgroup
+    constexpr int SW = TPR * CH;                        // chunks per slab
+    constexpr int NB = TPR == 8 ? 8 : 4;                // neighbours in flight per lane
+    constexpr int PARTS = SW <= 8 ? SP_PARTS : SP_PARTS_WIDE;
+    constexpr int SP_ITEMS = SP_RB + PARTS;
+    __shared__ int idx_s[NG][SP_SEG];
+    __shared__ float w_s[TRANSPOSED ? NG : 1][SP_SEG];
+    __shared__ float4 part_s[PARTS][SW];
+    __shared__ int row_b[SP_RB], row_e[SP_RB], row_slot[SP_RB], row_nseg[SP_RB];
+    __shared__ unsigned short item_row[SP_ITEMS], item_seg[SP_ITEMS];
+    __shared__ int nitems_s, next_s;
+
+    // ---- which slab, which 32 rows
+    int64_t bid = blockIdx.x;
+    int slab;
+    int64_t rg;
+    const int64_t nfull = sc.blocks_full * sc.full_rounds;
+    if (bid < nfull) {
+        const int64_t round = bid / sc.blocks_full, r = bid - round * sc.blocks_full;
+        slab = (int)(round * 8 + (r & 7));
+        rg = r >> 3;
+    } else {
+        const int64_t r = bid - nfull;
+        const int x = (int)(r & 7);
+        const int64_t k = r >> 3;
+        const int sl = x % sc.rem;
+        const int cnt = (8 - sl + sc.rem - 1) / sc.rem;     // XCDs that share this slab
+        slab = sc.full_rounds * 8 + sl;
+        rg = k * cnt + x / sc.rem;
+        if (rg >= sc.rowgroups) return;
+    }
+    const int64_t i0 = rg * SP_RB;
+    const int tid = threadIdx.x, g = tid / TPR, l = tid % TPR;
+    int cc[CH];                                           // this lane's float4 chunks
+    bool on[CH];
 #pragma unroll
-    for (int k = 0; k < CH; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (e > b) {
-        const float inv_row = 1.0f / (float)(e - b);
-        int p = b;
-        for (; p + 4 <= e; p += 4) {
-            int j[4];
-            float w[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) j[q] = colidx[p + q];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) w[q] = TRANSPOSED ? 1.0f / (float)(rowptr[j[q] + 1] - rowptr[j[q]]) : inv_row;
-            float4 v[4][CH];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int k = 0; k < CH; ++k) {
-                    const int c = t + k * tpr;
-                    v[q][k] = c < nchunks ? *reinterpret_cast<const float4*>(H + (int64_t)j[q] * ldh + 4 * c)
-                                          : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int k = 0; k < CH; ++k) {
-                    acc[k].x = __builtin_fmaf(v[q][k].x, w[q], acc[k].x);
-                    acc[k].y = __builtin_fmaf(v[q][k].y, w[q], acc[k].y);
-                    acc[k].z = __builtin_fmaf(v[q][k].z, w[q], acc[k].z);
-                    acc[k].w = __builtin_fmaf(v[q][k].w, w[q], acc[k].w);
-                }
+    for (int c = 0; c < CH; ++c) {
+        cc[c] = slab * SW + l + TPR * c;
+        on[c] = cc[c] < nchunks;
+    }
+
+    // ---- the block's item list: lanes 0..31 of wave 0 take a row each, two in-wave prefix sums place its items and slots
+    if (tid < 64) {
+        const int r = tid;
+        const int64_t i = i0 + r;
+        int rb = 0, re = 0;
+        const bool live = r < SP_RB && i < n;
+        if (live) { rb = rowptr[i]; re = rowptr[i + 1]; }
+        const int deg = re - rb;
+        const int ns = deg <= SP_SEG ? 1 : (deg + SP_SEG - 1) / SP_SEG;
+        const bool multi = live && ns > 1;
+        int slot_inc = multi ? ns : 0;                    // inclusive prefix of the slots multi-segment rows ask for
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(slot_inc, off);
+            if (tid >= off) slot_inc += t;
         }
-        for (; p < e; ++p) {
-            const int j = colidx[p];
-            const float inv = TRANSPOSED ? 1.0f / (float)(rowptr[j + 1] - rowptr[j]) : inv_row;
-#pragma unroll
-            for (int k = 0; k < CH; ++k) {
-                const int c = t + k * tpr;
-                if (c < nchunks) {
-                    float4 v = *reinterpret_cast<const float4*>(H + (int64_t)j * ldh + 4 * c);
-                    acc[k].x = __builtin_fmaf(v.x, inv, acc[k].x);
-                    acc[k].y = __builtin_fmaf(v.y, inv, acc[k].y);
-                    acc[k].z = __builtin_fmaf(v.z, inv, acc[k].z);
-                    acc[k].w = __builtin_fmaf(v.w, inv, acc[k].w);
+        const int slot_base = slot_inc - (multi ? ns : 0);
+        const bool fits = multi && slot_base + ns <= PARTS;   // else one group walks the whole row (SP_SERIAL)
+        // the (full, 64-neighbour) items of split rows go to the front of the list, so that a hub never starts last
+        // (a row whose sums found no slot is walked whole by one group: those first of all)
+        const bool serial = multi && !fits;
+        int serial_inc = serial ? 1 : 0, heavy_inc = fits ? ns : 0, light_inc = (live && !multi) ? 1 : 0;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t0 = __shfl_up(heavy_inc, off), t1 = __shfl_up(light_inc, off), t2 = __shfl_up(serial_inc, off);
+            if (tid >= off) { heavy_inc += t0; light_inc += t1; serial_inc += t2; }
+        }
+        const int heavy_total = __shfl(heavy_inc, 63), light_total = __shfl(light_inc, 63), serial_total = __shfl(serial_inc, 63);
+        const int item_base = serial ? serial_inc - 1 : fits ? serial_total + heavy_inc - ns : serial_total + heavy_total + light_inc - 1;
+        const int item_inc = serial_total + heavy_total + light_total;
+        if (r < SP_RB) {
+            row_b[r] = rb;
+            row_e[r] = re;
+            row_slot[r] = fits ? slot_base : -1;
+            row_nseg[r] = fits ? ns : 1;
+            if (live) {
+                if (fits) {
+                    for (int sg = 0; sg < ns; ++sg) { item_row[item_base + sg] = (unsigned short)r; item_seg[item_base + sg] = (unsigned short)sg; }
+                } else {
+                    item_row[item_base] = (unsigned short)r;
+                    item_seg[item_base] = (unsigned short)(multi ? SP_SERIAL : 0);
                 }
             }
         }
+        if (tid == 63) { nitems_s = item_inc; next_s = 0; }
     }
+    __syncthreads();
+    const int nitems = nitems_s;
+
+    for (;;) {
+        int it = 0;
+        if (l == 0) it = atomicAdd(&next_s, 1);
+        it = __shfl(it, 0, TPR);
+        if (it >= nitems) break;
+        const int r = item_row[it], sgi = item_seg[it];
+        const int rb = row_b[r], re = row_e[r];
+        const float inv_row = re > rb ? 1.0f / (float)(re - rb) : 0.0f;
+        int p0 = rb, p1 = re;
+        if (sgi != SP_SERIAL) {
+            p0 = rb + sgi * SP_SEG;
+            p1 = p0 + SP_SEG < re ? p0 + SP_SEG : re;
+        }
+        float4 total[CH];
+        for (int ps = p0; ps < p1 || ps == p0; ps += SP_SEG) {          // one pass unless SP_SERIAL (an empty row: one pass of nothing)
+            const int pe = ps + SP_SEG < p1 ? ps + SP_SEG : p1;
+            const int cnt = pe - ps;
+            // the segment's column indices: one coalesced read by the 8 lanes into the group's LDS slot
 #pragma unroll
-    for (int k = 0; k < CH; ++k) {
-        const int c = t + k * tpr;
-        if (c < nchunks) *reinterpret_cast<float4*>(out + i * ldo + 4 * c) = acc[k];
+            for (int q = 0; q < (SP_SEG + TPR - 1) / TPR; ++q) {
+                const int k = l + TPR * q;
+                if (k < cnt) {
+                    const int j = colidx[ps + k];
+                    idx_s[g][k] = j;
+                    if (TRANSPOSED) w_s[g][k] = 1.0f / (float)(rowptr[j + 1] - rowptr[j]);
+                }
+            }
+            float4 acc[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < cnt; k += NB) {                         // LDS serves a wave's own writes and reads in order
+                float4 v[NB][CH];
+                float w[NB];
+#pragma unroll
+                for (int q = 0; q < NB; ++q) {
+                    const bool in = k + q < cnt;
+                    const int j = in ? idx_s[g][k + q] : 0;
+                    w[q] = TRANSPOSED ? (in ? w_s[g][k + q] : 0.0f) : inv_row;
+#pragma unroll
+                    for (int c = 0; c < CH; ++c)
+                        v[q][c] = (in && on[c]) ? *reinterpret_cast<const float4*>(H + (int64_t)j * ldh + 4 * cc[c])
+                                                : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int q = 0; q < NB; ++q)
+                    if (k + q < cnt) {
+#pragma unroll
+                        for (int c = 0; c < CH; ++c) {
+                            acc[c].x = __builtin_fmaf(v[q][c].x, w[q], acc[c].x);
+                            acc[c].y = __builtin_fmaf(v[q][c].y, w[q], acc[c].y);
+                            acc[c].z = __builtin_fmaf(v[q][c].z, w[q], acc[c].z);
+                            acc[c].w = __builtin_fmaf(v[q][c].w, w[q], acc[c].w);
+                        }
+                    }
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if (ps == p0) total[c] = acc[c];
+                else {
+                    total[c].x = total[c].x + acc[c].x; total[c].y = total[c].y + acc[c].y;
+                    total[c].z = total[c].z + acc[c].z; total[c].w = total[c].w + acc[c].w;
+                }
+            }
+            if (ps + SP_SEG >= p1) break;
+        }
+        const int slot = row_slot[r];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (slot < 0) {
+                if (on[c]) *reinterpret_cast<float4*>(out + (i0 + r) * ldo + 4 * cc[c]) = total[c];
+            } else {
+                part_s[slot + sgi][l + TPR * c] = total[c];
+            }
+        }
+    }
+    __syncthreads();
+    // rows whose segment sums met in LDS: added in ascending segment order
+    for (int r = g; r < SP_RB; r += NG) {
+        const int slot = row_slot[r];
+        if (slot < 0) continue;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            float4 t = part_s[slot][l + TPR * c];
+            for (int sg = 1; sg < row_nseg[r]; ++sg) {
+                const float4 a = part_s[slot + sg][l + TPR * c];
+                t.x = t.x + a.x; t.y = t.y + a.y; t.z = t.z + a.z; t.w = t.w + a.w;
+            }
+            if (on[c]) *reinterpret_cast<float4*>(out + (i0 + r) * ldo + 4 * cc[c]) = t;
+        }
     }
 }
 
-// XCD-sliced variant for a dense operand that does not fit one XCD's 4 MB L2: the columns are cut into slabs of `sc` <= 8
-// float4 chunks whose n rows fit an L2 (<= 2.5 MB), a group of 8 threads owns a row, and workgroup b works on slab (b % 8) + 8 * round.  Workgroups are dealt
-// round-robin to the 8 XCDs, so every gather of a slab is issued from the XCD whose L2 holds that slab after first touch,
-// instead of each XCD streaming the whole of H through its L2 from the Infinity Cache (measured before: 0.89 GB across
-// the L2 boundary for a 58 MB operand).  A wrong guess about the placement costs speed only.  Same arithmetic per column.
-template <int TPR, bool TRANSPOSED = false>
-__global__ void __launch_bounds__(256)
-k_spmm_mean_xcd(int64_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
-                const float* __restrict__ H, int64_t ldh, int nchunks, int sc, int64_t rowgroups, float* __restrict__ out,
-                int64_t ldo) {
-    constexpr int CH = 1;                          // sc <= TPR: one float4 chunk per thread
-    const int64_t b = blockIdx.x;
-    const int64_t round = b / (8 * rowgroups);
-    const int slab = (int)(round * 8 + (b & 7));
-    const int64_t rg = (b >> 3) % rowgroups;
-    const int r = threadIdx.x / TPR, t = threadIdx.x % TPR;
-    const int64_t i = rg * (256 / TPR) + r;
-    if (i >= n) return;
-    const int c0 = slab * sc;
-    bool on[CH];
-    int cc[CH];
-#pragma unroll
-    for (int k = 0; k < CH; ++k) {
-        cc[k] = c0 + t + k * TPR;
-        on[k] = (t + k * TPR < sc) && (cc[k] < nchunks);
-    }
-    const int bgn = rowptr[i], end = rowptr[i + 1];
-    float4 acc[CH];
-#pragma unroll
-    for (int k = 0; k < CH; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (end > bgn) {
-        const float inv_row = 1.0f / (float)(end - bgn);
-        int p = bgn;
-        for (; p + 4 <= end; p += 4) {
-            int j[4];
-            float w[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) j[q] = colidx[p + q];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) w[q] = TRANSPOSED ? 1.0f / (float)(rowptr[j[q] + 1] - rowptr[j[q]]) : inv_row;
-            float4 v[4][CH];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int k = 0; k < CH; ++k)
-                    v[q][k] = on[k] ? *reinterpret_cast<const float4*>(H + (int64_t)j[q] * ldh + 4 * cc[k])
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int k = 0; k < CH; ++k) {
-                    acc[k].x = __builtin_fmaf(v[q][k].x, w[q], acc[k].x);
-                    acc[k].y = __builtin_fmaf(v[q][k].y, w[q], acc[k].y);
-                    acc[k].z = __builtin_fmaf(v[q][k].z, w[q], acc[k].z);
-                    acc[k].w = __builtin_fmaf(v[q][k].w, w[q], acc[k].w);
-                }
-        }
-        for (; p < end; ++p) {
-            const int j = colidx[p];
-            const float inv = TRANSPOSED ? 1.0f / (float)(rowptr[j + 1] - rowptr[j]) : inv_row;
-#pragma unroll
-            for (int k = 0; k < CH; ++k)
-                if (on[k]) {
-                    const float4 v = *reinterpret_cast<const float4*>(H + (int64_t)j * ldh + 4 * cc[k]);
-                    acc[k].x = __builtin_fmaf(v.x, inv, acc[k].x);
-                    acc[k].y = __builtin_fmaf(v.y, inv, acc[k].y);
-                    acc[k].z = __builtin_fmaf(v.z, inv, acc[k].z);
-                    acc[k].w = __builtin_fmaf(v.w, inv, acc[k].w);
-                }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < CH; ++k)
-        if (on[k]) *reinterpret_cast<float4*>(out + i * ldo + 4 * cc[k]) = acc[k];
-}
-
-// scalar fallback for widths / strides that are not 16-byte friendly
+// scalar fallback for widths / strides that are not 16-byte friendly: same segment rule, one thread per column
 template <bool TRANSPOSED = false>
 __global__ void k_spmm_mean_scalar(int64_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
                                    const float* __restrict__ H, int64_t ldh, int64_t d, float* __restrict__ out, int64_t ldo) {
@@ -162,13 +234,18 @@ __global__ void k_spmm_mean_scalar(int64_t n, const int32_t* __restrict__ rowptr
     const int b = rowptr[i], e = rowptr[i + 1];
     const float inv_row = e > b ? 1.0f / (float)(e - b) : 0.0f;
     for (int64_t c = threadIdx.x; c < d; c += blockDim.x) {
-        float acc = 0.0f;
-        for (int p = b; p < e; ++p) {
-            const int j = colidx[p];
-            const float inv = TRANSPOSED ? 1.0f / (float)(rowptr[j + 1] - rowptr[j]) : inv_row;
-            acc = __builtin_fmaf(H[(int64_t)j * ldh + c], inv, acc);
+        float total = 0.0f;
+        for (int s0 = b; s0 < e; s0 += SP_SEG) {
+            const int s1 = s0 + SP_SEG < e ? s0 + SP_SEG : e;
+            float acc = 0.0f;
+            for (int p = s0; p < s1; ++p) {
+                const int j = colidx[p];
+                const float inv = TRANSPOSED ? 1.0f / (float)(rowptr[j + 1] - rowptr[j]) : inv_row;
+                acc = __builtin_fmaf(H[(int64_t)j * ldh + c], inv, acc);
+            }
+            total = s0 == b ? acc : total + acc;
         }
-        out[i * ldo + c] = acc;
+        out[i * ldo + c] = total;
     }
 }
 
@@ -297,46 +374,34 @@ int launch_copy2d(int64_t n, int w, const float* src, int64_t lds_, float* dst, 
 
 using namespace gm;
 
-// n output rows (rowptr[0..n]); hn = rows of the dense operand H (>= n when a rank aggregates only its node block)
+// n output rows (rowptr[0..n]); the dense operand H may have more rows (a rank aggregates only its node block)
 template <bool TRANSPOSED>
 static int launch_spmm(int64_t n, const int32_t* rowptr, const int32_t* colidx, const float* H, int64_t ldh, int64_t d,
                        float* out, int64_t ldo, hipStream_t s, int64_t hn = 0) {
     if (hn < n) hn = n;
     const bool vec = (d % 4 == 0) && (ldh % 4 == 0) && (ldo % 4 == 0) && aligned(H, 16) && aligned(out, 16);
-    const int nchunks = (int)(d / 4);
-    // threads per row: a power of two in [4,64]; CH chunks per thread covers the row
-    int tpr = 4;
-    while (tpr < 64 && tpr < nchunks) tpr <<= 1;
-    const int ch = (nchunks + tpr - 1) / tpr;
-    if (!vec || ch > 4) {
-        hipLaunchKernelGGL((k_spmm_mean_scalar<TRANSPOSED>), dim3((unsigned)n), dim3(vec ? 256 : 128), 0, s, n, rowptr, colidx, H,
-                           ldh, d, out, ldo);
+    if (!vec) {
+        hipLaunchKernelGGL((k_spmm_mean_scalar<TRANSPOSED>), dim3((unsigned)n), dim3(128), 0, s, n, rowptr, colidx, H, ldh, d, out, ldo);
         GM_LAUNCH_CHECK();
         return GM_OK;
     }
-#ifndef GM_SPMM_NO_XCD   // (exploration builds define it to time the plain kernel)
-    // operand larger than an L2, rows few enough that an 8-chunk (128 B wide) slab of all of them fits one (n <= 20480):
-    // the leading multiple of 64 chunks goes through the XCD-sliced kernel (8 slabs per round of the 8 XCDs, every lane
-    // busy; 6- and 9-chunk slabs measured no better than the plain kernel), the remaining columns through the plain one
-    // (and enough output rows to fill the chip with 32-row workgroups per slab: a rank's 1719-row block measured slower)
-    if (hn * d * 4 > (6ll << 20) && hn * 128 <= (5ll << 19) && nchunks >= 64 && n >= 4096) {
-        const int nx = (nchunks / 64) * 64;
-        const int64_t rowgroups = (n + 31) / 32;
-        const int64_t blocks = (int64_t)(nx / 8) * rowgroups;
-        if (blocks < (1ll << 31)) {
-            hipLaunchKernelGGL((k_spmm_mean_xcd<8, TRANSPOSED>), dim3((unsigned)blocks), dim3(256), 0, s, n, rowptr, colidx, H, ldh,
-                               nx, 8, rowgroups, out, ldo);
-            GM_LAUNCH_CHECK();
-            if (nx == nchunks) return GM_OK;
-            return launch_spmm<TRANSPOSED>(n, rowptr, colidx, H + 4 * nx, ldh, d - 4 * nx, out + 4 * nx, ldo, s, hn);
-        }
+    const int nchunks = (int)(d / 4);
+    const bool wide = hn > 20480;                         // a 128-byte slab of all rows no longer fits an L2
+    const int nslabs = wide ? (nchunks + 127) / 128 : (nchunks + 7) / 8;
+    SpmmSched sc;
+    sc.rowgroups = (n + SP_RB - 1) / SP_RB;
+    sc.full_rounds = nslabs / 8;
+    sc.rem = nslabs % 8;
+    sc.blocks_full = 8 * sc.rowgroups;
+    sc.k_rem = 0;
+    if (sc.rem) {
+        const int cnt_min = 8 / sc.rem;                    // the slab shared by the fewest XCDs
+        sc.k_rem = (sc.rowgroups + cnt_min - 1) / cnt_min;
     }
-#endif
-    const int rows_per_block = 256 / tpr;
-    dim3 grid((unsigned)((n + rows_per_block - 1) / rows_per_block)), block(256);
-    if (ch == 1) hipLaunchKernelGGL((k_spmm_mean<1, TRANSPOSED>), grid, block, 0, s, n, rowptr, colidx, H, ldh, nchunks, tpr, out, ldo);
-    else if (ch == 2) hipLaunchKernelGGL((k_spmm_mean<2, TRANSPOSED>), grid, block, 0, s, n, rowptr, colidx, H, ldh, nchunks, tpr, out, ldo);
-    else hipLaunchKernelGGL((k_spmm_mean<4, TRANSPOSED>), grid, block, 0, s, n, rowptr, colidx, H, ldh, nchunks, tpr, out, ldo);
+    const int64_t blocks = sc.blocks_full * sc.full_rounds + 8 * sc.k_rem;
+    GM_REQUIRE(blocks > 0 && blocks < (1ll << 31), "SpMM grid out of range");
+    if (wide) hipLaunchKernelGGL((k_spmm_seg<TRANSPOSED, 64, 2>), dim3((unsigned)blocks), dim3(256), 0, s, n, rowptr, colidx, H, ldh, nchunks, out, ldo, sc);
+    else hipLaunchKernelGGL((k_spmm_seg<TRANSPOSED, 8, 1>), dim3((unsigned)blocks), dim3(256), 0, s, n, rowptr, colidx, H, ldh, nchunks, out, ldo, sc);
     GM_LAUNCH_CHECK();
     return GM_OK;
 }

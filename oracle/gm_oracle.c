@@ -355,8 +355,12 @@ void gmo_bitmap_from_upper_edges(int64_t n, int64_t wpr, int64_t m, const int32_
 }
 
 /* ------------------------------------------------------------------ building blocks */
-/* model/gnn.py:60-61  A @ H with A = D^-1 A (diffusion.py:255-256): out[i] = sum_j (1/deg_i) * H[j],
- * neighbours in ascending j, one fmaf per term. */
+/* model/gnn.py:60-61  A @ H with A = D^-1 A (diffusion.py:255-256): out[i] = sum_j (1/deg_i) * H[j].
+ * Order: a row's neighbours (ascending j) are cut into segments of GMO_SPMM_SEG = 64; a segment is one fmaf chain
+ * acc = fmaf(H[j], 1/deg_i, acc) from 0 over its neighbours in order; the row is the segment sums added in ascending segment
+ * order ((s0 + s1) + s2 ...).  Rows of up to 64 neighbours are therefore a single chain; the cut is what lets the HIP kernel
+ * spread a hub row (amazon_computer's largest degree is ~3000) over many lanes and still produce these bits. */
+#define GMO_SPMM_SEG 64
 void gmo_spmm_mean(int64_t n, const int32_t* rowptr, const int32_t* colidx, const float* H, int64_t ldh,
                    int64_t d, float* out, int64_t ldo) {
 #pragma omp parallel for schedule(dynamic, 64)
@@ -366,11 +370,27 @@ void gmo_spmm_mean(int64_t n, const int32_t* rowptr, const int32_t* colidx, cons
         int32_t b = rowptr[i], e = rowptr[i + 1];
         if (e == b) continue;
         float inv = 1.0f / (float)(e - b);
-        for (int32_t p = b; p < e; ++p) {
-            const float* hrow = H + (int64_t)colidx[p] * ldh;
+        if (e - b <= GMO_SPMM_SEG) {
+            for (int32_t p = b; p < e; ++p) {
+                const float* hrow = H + (int64_t)colidx[p] * ldh;
 #pragma omp simd
-            for (int64_t c = 0; c < d; ++c) o[c] = fmaf(hrow[c], inv, o[c]);
+                for (int64_t c = 0; c < d; ++c) o[c] = fmaf(hrow[c], inv, o[c]);
+            }
+            continue;
         }
+        float* seg = (float*)malloc(sizeof(float) * (size_t)d);
+        for (int32_t s0 = b; s0 < e; s0 += GMO_SPMM_SEG) {
+            int32_t s1 = s0 + GMO_SPMM_SEG < e ? s0 + GMO_SPMM_SEG : e;
+            for (int64_t c = 0; c < d; ++c) seg[c] = 0.0f;
+            for (int32_t p = s0; p < s1; ++p) {
+                const float* hrow = H + (int64_t)colidx[p] * ldh;
+#pragma omp simd
+                for (int64_t c = 0; c < d; ++c) seg[c] = fmaf(hrow[c], inv, seg[c]);
+            }
+            if (s0 == b) for (int64_t c = 0; c < d; ++c) o[c] = seg[c];
+            else for (int64_t c = 0; c < d; ++c) o[c] = o[c] + seg[c];
+        }
+        free(seg);
     }
 }
 

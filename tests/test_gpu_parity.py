@@ -138,6 +138,72 @@ def test_spmm_mean(dev, n, d, density):
     check_float(ops.spmm_mean(adj, t_(H, dev)), orc.spmm_mean(rp, ci, H), 1e-6, "spmm")
 
 
+def test_spmm_mean_operand_larger_than_the_l2s(dev):
+    """n > 20480: the kernel runs with 2 KB slabs (one wave per item) and 16 LDS slots for segment sums; hubs of 700 and of
+    3000 neighbours (the second one exceeds the slots and is walked by one wave); d = 576 leaves a ragged second slab."""
+    ops = _ops()
+    n, d = 21000, 576
+    rs = np.random.RandomState(4)
+    m = 60000
+    i, j = rs.randint(0, n, m), rs.randint(0, n, m)
+    hubs = [(5, rs.choice(n, 700, replace=False)), (6, rs.choice(n, 3000, replace=False))]
+    ei = np.concatenate([i] + [np.full(len(c), h) for h, c in hubs])
+    ej = np.concatenate([j] + [c for h, c in hubs])
+    keep = ei != ej
+    lo, hi = np.minimum(ei, ej)[keep].astype(np.int32), np.maximum(ei, ej)[keep].astype(np.int32)
+    bits = ops.bitmap_from_upper_edges(n, t_(lo, dev), t_(hi, dev))
+    adj = ops.adjacency_from_bitmap(bits, n)
+    rp, ci = orc.csr_from_bitmap(bits_np(bits), n)
+    assert np.diff(rp).max() >= 3000
+    H = rs.normal(size=(n, d)).astype(np.float32)
+    check_float(ops.spmm_mean(adj, t_(H, dev)), orc.spmm_mean(rp, ci, H), 1e-6, "spmm, 2 KB slabs")
+
+
+def skewed_sym_dense(n, mean_deg, max_deg, seed):
+    """Chung-Lu style graph with a power-law degree sequence (a few hubs of about max_deg neighbours): the degree
+    distribution of the real datasets and of what a trained model samples, which an Erdos-Renyi prior draw does not have."""
+    rs = np.random.RandomState(seed)
+    w = (np.arange(n) + 1.0) ** -0.75
+    w = w / w.sum() * mean_deg * n
+    w = np.minimum(w, max_deg)
+    rs.shuffle(w)
+    p = w / w.sum()
+    m = int(mean_deg * n / 2)
+    i, j = rs.choice(n, size=m, p=p), rs.choice(n, size=m, p=p)
+    d = np.zeros((n, n), np.int64)
+    d[i, j] = 1
+    d[j, i] = 1
+    d[np.arange(n), np.arange(n)] = 0
+    return d
+
+
+@pytest.mark.parametrize("n,d,mean_deg,max_deg", [(3000, 576, 30, 2500), (1000, 64, 20, 999), (5000, 512, 36, 3000),
+                                                  (300, 48, 100, 299), (700, 20, 40, 600)])
+def test_spmm_mean_skewed_degrees_and_hub_rows(dev, n, d, mean_deg, max_deg):
+    """Rows far longer than a 64-neighbour segment (hubs of thousands of neighbours, several of them in one 32-row block so
+    that the block's LDS slots for segment sums run out and a row is walked by a single group): still the oracle's bits, for
+    the forward operator; the transposed one (backward) against float64."""
+    ops = _ops()
+    dense = skewed_sym_dense(n, mean_deg, max_deg, n + d)
+    dense[:8, 8:] = 1                      # eight consecutive hub rows of ~n neighbours: 8 * ceil(n/64) segment sums > 96 slots
+    dense[8:, :8] = 1
+    ref_bits = orc.bitmap_from_dense(dense)
+    rp, ci = orc.csr_from_bitmap(ref_bits, n)
+    assert np.diff(rp).max() > 64
+    H = np.random.RandomState(d).normal(size=(n, d)).astype(np.float32)
+    adj = ops.adjacency_from_bitmap(bits_t(ref_bits, dev), n)
+    got = ops.spmm_mean(adj, t_(H, dev))
+    check_float(got, orc.spmm_mean(rp, ci, H), 1e-6, "spmm, skewed degrees")
+    deg = np.maximum(dense.sum(1), 1).astype(np.float64)
+    np.testing.assert_allclose(got.cpu().numpy(), (dense / deg[:, None]) @ H.astype(np.float64), atol=2e-5, rtol=1e-5)
+    from graphmaker_amd import _lib as L
+    out = torch.empty((n, d), dtype=torch.float32, device=dev)
+    Hd = t_(H, dev)
+    L.call("gm_spmm_mean_bwd", L.I64(n), L.ptr(adj.rowptr), L.ptr(adj.colidx), L.ptr(Hd), L.I64(d), L.I64(d), L.ptr(out),
+           L.I64(d), L.stream_ptr())
+    np.testing.assert_allclose(out.cpu().numpy(), (dense / deg[None, :]) @ H.astype(np.float64), atol=5e-5, rtol=1e-5)
+
+
 @pytest.mark.parametrize("M,N,K,relu,bias", [(1, 16, 1, True, True), (67, 32, 22, True, True), (200, 304, 304, True, True),
                                              (130, 128, 152, False, True), (257, 40, 131, False, False),
                                              (300, 1534, 1744, False, True),
