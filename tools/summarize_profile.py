@@ -32,6 +32,8 @@ def main():
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 name = row["Kernel_Name"].split("(")[0].replace("void ", "")
+                if name.startswith("gm::k_pair_score_sample"):      # the product instantiation <false> and the debug one
+                    name = "gm::k_pair_score_sample"
                 if "gm::" not in name:
                     continue
                 acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
@@ -49,6 +51,11 @@ def main():
                 pair["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_launch"] / 1024
                 / (pair["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8))
             out["_derived"]["note"] = "SQ_VALU_MFMA_BUSY_CYCLES summed over 1024 SIMDs / (GRBM_GUI_ACTIVE/8 XCDs)"
+    # the aggregation kernel: counter traffic against its compulsory bytes is the figure to watch (wasted re-reads)
+    sp = out.get("gm::k_spmm_seg<false, 8, 1>", {})
+    if {"FETCH_SIZE", "WRITE_SIZE"} <= set(sp):
+        out.setdefault("_derived", {})["spmm_seg_hbm_traffic_bytes_per_launch_mean"] = (
+            2 * sp["FETCH_SIZE"]["mean_per_launch"] + sp["WRITE_SIZE"]["mean_per_launch"]) * 1024
     with open(prefix + "_pmc_summary.json", "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps(out.get("_derived"), indent=1))
