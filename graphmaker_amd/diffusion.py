@@ -125,6 +125,8 @@ class BaseModel(nn.Module):
         # running its GEMM (same bits either way, gm_onehot.hip); break-even is near 9% ones at the reference's hidden sizes
         self._sparse_X = float(X_marginal[:, 1].float().mean()) < 0.06
         self._pair_ws = None
+        # "f32" (exact, default) | "bf16x3" | "bf16": opt-in matrix-core precision of the pair MLP's hidden layer (ops.py)
+        self.pair_precision = "f32"
         self._prof = None          # None, or dict phase -> [(start_event, end_event)] (bench.py / profiling)
 
     class _Phase:
@@ -324,7 +326,7 @@ class BaseModel(nn.Module):
             before_pair()
         with self.phase("pair"):      # a rank's two folded chunks go into ONE launch (shared tile queue)
             ops.pair_score_sample(h, W1, b1, W2, b2, bits_t, tab_E, seed=seed, step=step, u=u, row_ranges=ranges,
-                                  out_upper=upper, workspace=self._pair_ws)
+                                  out_upper=upper, workspace=self._pair_ws, precision=self.pair_precision)
         if plan is not None:
             return A_t, self._exchange_edges(plan, upper, group)
         with self.phase("symmetrize"):
@@ -530,7 +532,8 @@ class ModelSync(BaseModel):
         upper = self._buf("upper", (plan.padded_pair_rows, bits_t.shape[1]), torch.int32, dev, zero=True)
         with self.phase("pair"):
             ops.pair_score_sample(h, W1, b1, W2, b2, bits_t, tab_E, seed=seed, step=t, u=uE,
-                                  row_ranges=plan.pair_chunks(), out_upper=upper, workspace=self._pair_ws)
+                                  row_ranges=plan.pair_chunks(), out_upper=upper, workspace=self._pair_ws,
+                                  precision=self.pair_precision)
         bits_s = self._exchange_edges(plan, upper, group)
         with self.phase("allgather_X"):
             x_on_wire.wait()

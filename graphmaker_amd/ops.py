@@ -303,10 +303,16 @@ def check_pair_workspace(workspace):
                            "adjacency of this trajectory is void (see include/graphmaker_hip.h)")
 
 
+PAIR_PRECISIONS = {"f32": 0, "bf16x3": 3, "bf16": 1}
+
+
 def pair_score_sample(h, W1, b1, W2, b2, bits_t, tab, *, seed=0, step=0, u=None, row_begin=0, row_end=None,
-                      row_ranges=None, out_upper=None, workspace=None, want_debug=False):
+                      row_ranges=None, out_upper=None, workspace=None, want_debug=False, precision="f32"):
     """All pairs i<j of rows [row_begin,row_end) -- or of up to four ascending, disjoint `row_ranges` [(b0,e0),...] in
-    one launch: returns the upper-triangle bitmap of E_s (and (P,2) logits / posteriors when want_debug)."""
+    one launch: returns the upper-triangle bitmap of E_s (and (P,2) logits / posteriors when want_debug).
+    precision: "f32" (exact, the default) or the opt-in "bf16x3" / "bf16" matrix-core paths (include/graphmaker_hip.h)."""
+    if precision not in PAIR_PRECISIONS:
+        raise ValueError(f"precision must be one of {sorted(PAIR_PRECISIONS)}, got {precision!r}")
     require(h, torch.float32, "h")
     require(bits_t, torch.int32, "bits_t")
     n, hE = h.shape
@@ -330,9 +336,14 @@ def pair_score_sample(h, W1, b1, W2, b2, bits_t, tab, *, seed=0, step=0, u=None,
         row_ranges = [(row_begin, row_end)]
     flat = [int(v) for be in row_ranges for v in be]
     ranges_host = (C.c_int64 * len(flat))(*flat)
-    L.call("gm_pair_score_sample_ranges", I64(n), I64(hE), ptr(h), ptr(W1), ptr(b1), ptr(W2), ptr(b2), ptr(bits_t),
-           I64(wpr), tab_host, I32(len(flat) // 2), ranges_host, ptr(u), U64(seed), U32(step), ptr(out_upper), ptr(lg),
-           ptr(po), ptr(workspace), stream_ptr())
+    if precision == "f32":
+        L.call("gm_pair_score_sample_ranges", I64(n), I64(hE), ptr(h), ptr(W1), ptr(b1), ptr(W2), ptr(b2), ptr(bits_t),
+               I64(wpr), tab_host, I32(len(flat) // 2), ranges_host, ptr(u), U64(seed), U32(step), ptr(out_upper), ptr(lg),
+               ptr(po), ptr(workspace), stream_ptr())
+    else:
+        L.call("gm_pair_score_sample_bf16", I64(n), I64(hE), ptr(h), ptr(W1), ptr(b1), ptr(W2), ptr(b2), ptr(bits_t),
+               I64(wpr), tab_host, I32(len(flat) // 2), ranges_host, ptr(u), U64(seed), U32(step), ptr(out_upper), ptr(lg),
+               ptr(po), ptr(workspace), I32(PAIR_PRECISIONS[precision]), stream_ptr())
     if own_workspace:
         check_pair_workspace(workspace)
     return (out_upper, lg, po) if want_debug else out_upper

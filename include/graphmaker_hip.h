@@ -184,6 +184,18 @@ int gm_pair_score_sample_ranges(int64_t n, int64_t hE, const float* h, const flo
                                 uint32_t* out_upper, float* logits_dbg, float* post_dbg, void* workspace,
                                 gm_stream_t stream);
 
+/* OPT-IN reduced precision (never the default): the same loop with the 128x128 product hid = W1 (h_i * h_j) on the bf16
+ * matrix cores, f32 accumulation, everything else (z products, second layer, softmax, posterior, draw) in f32 as above.
+ *   nprod = 3 ("bf16x3"): W1 and z are split into bf16 head + tail and three products are summed (error 2^-16 relative per
+ *                         product): logits stay within the f32 tolerance of the reference (atol 2e-5);
+ *   nprod = 1 ("bf16")  : heads only (2^-8 relative per product; logits atol ~2e-2).
+ * Draws are not bit-identical to gm_pair_score_sample_ranges: a draw may differ where |u*(p0+p1) - p1| is within the posterior
+ * error.  Same arguments and workspace as gm_pair_score_sample_ranges. */
+int gm_pair_score_sample_bf16(int64_t n, int64_t hE, const float* h, const float* W1, const float* b1, const float* W2,
+                              const float* b2, const uint32_t* bits_t, int64_t wpr, const float* tab, int nranges,
+                              const int64_t* row_ranges, const float* u, uint64_t seed, uint32_t step, uint32_t* out_upper,
+                              float* logits_dbg, float* post_dbg, void* workspace, int nprod, gm_stream_t stream);
+
 /* ---- attribute posterior + draw: model/diffusion.py:879-895 + sample_X :214-237 ----
  * logits (n,F,2); tab device (F,8) per-attribute posterior tables; x_s (n,F) uint8; onehot_out optional (n,2F).
  * Only nodes [v_begin, v_end) are processed (all pointers address the full arrays): the per-GPU shard. */

@@ -365,6 +365,73 @@ def test_structure_step_vs_reference_and_oracle(dev, name):
             pytest.fail(f"{len(idx)} threshold-level flips vs the reference (not expected on these fixtures)")
 
 
+# opt-in reduced precision of the pair MLP's hidden layer: stated tolerances vs the REFERENCE's logits / posteriors, and the
+# bound on draws that may differ from the exact f32 path
+BF16_TOL = {"bf16x3": dict(logit=2e-5, post=2e-6, knife=1e-5), "bf16": dict(logit=3e-2, post=5e-3, knife=5e-3)}
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("name", ["sync_small", "sync_mid", "tower_full"])
+def test_pair_kernel_bf16_paths_within_tolerance_of_the_reference(dev, name, precision):
+    """gm_pair_score_sample_bf16 (never the default): logits and posteriors within the stated tolerance of the reference's
+    own (fixtures), and every draw that differs from the exact f32 kernel's sits within `knife` of its threshold (counted).
+    bf16x3 keeps the f32 tolerances; plain bf16 has the tolerance of an 8-bit mantissa."""
+    ops = _ops()
+    tol = BF16_TOL[precision]
+    cfg, g, model, *_ = _models(name, dev)
+    N, seed, T = cfg["N"], cfg["seed"], cfg["T"]
+    ns = model.noise_schedule
+    W1, b1, W2, b2 = model.graph_encoder.pred_E.pair_params()
+    iu, ju = np.triu_indices(N, 1)
+    flips = 0
+    for t in range(T, 0, -1):
+        ref_bits, _ = _bits_from_nz(g[f"e{t}_E_in_nz"], N)
+        tab = model.transition.table_E(ns.alphas_host[t], ns.alpha_bars_host[t - 1], ns.alpha_bars_host[t])
+        u = orc.uniform_E(seed, t, N)
+        h_ref = t_(g[f"e{t}_h"], dev)
+        up, lg, po = ops.pair_score_sample(h_ref, W1, b1, W2, b2, bits_t(ref_bits, dev), tab, u=t_(u, dev), want_debug=True,
+                                           precision=precision)
+        np.testing.assert_allclose(lg.cpu().numpy(), g[f"e{t}_pair_logits"], atol=tol["logit"], rtol=1e-5)
+        po = po.cpu().numpy()
+        np.testing.assert_allclose(po, g[f"e{t}_E_prob"], atol=tol["post"], rtol=1e-5)
+        exact = ops.pair_score_sample(h_ref, W1, b1, W2, b2, bits_t(ref_bits, dev), tab, u=t_(u, dev))
+        a, b = gu.upper_bit(bits_np(up), iu, ju), gu.upper_bit(bits_np(exact), iu, ju)
+        bad = np.flatnonzero(a != b)
+        far = np.abs(u[bad] * (po[bad, 0] + po[bad, 1]) - po[bad, 1]) > tol["knife"]
+        assert not far.any(), f"t={t}: {int(far.sum())} draws differ from the f32 path away from their threshold"
+        flips += len(bad)
+        # the product instantiation (no debug outputs) and in-kernel Philox give the same draws as the debug one
+        up2 = ops.pair_score_sample(h_ref, W1, b1, W2, b2, bits_t(ref_bits, dev), tab, seed=seed, step=t, precision=precision)
+        assert torch.equal(ops.symmetrize_upper(up2, N), ops.symmetrize_upper(up, N))
+    print(f"{name} {precision}: {flips} draws differ from the f32 path (all within {tol['knife']} of their threshold)")
+    if precision == "bf16x3":
+        assert flips <= 2
+
+
+def test_pair_kernel_bf16x3_full_size_agrees_with_f32(dev):
+    """amazon_computer size, ragged tiles, several row ranges: the bf16x3 path draws the same graph as the f32 path except
+    for at most a handful of threshold-level pairs out of 94.5 million; whole-step use through model.pair_precision."""
+    ops = _ops()
+    n = 13752
+    g = torch.Generator(device="cpu").manual_seed(2)
+    h = (torch.randn(n, 128, generator=g) * 0.4).to(dev)
+    W1 = (torch.randn(128, 128, generator=g) / 11).to(dev)
+    b1 = (torch.randn(128, generator=g) * 0.1).to(dev)
+    W2 = (torch.randn(2, 128, generator=g) / 11).to(dev)
+    b2 = torch.tensor([3.0, -3.0], device=dev)
+    Em = np.array([1 - 2.6e-3, 2.6e-3], np.float32)
+    bits = ops.prior_E(n, float(Em[0]), float(Em[1]), dev, seed=3)
+    tab = orc.posterior_table_E(Em, 0.58304191, 0.84701216, 0.49384356)
+    exact = ops.pair_score_sample(h, W1, b1, W2, b2, bits, tab, seed=9, step=2)
+    out = torch.zeros_like(exact)
+    for rng in ([(0, 5000), (5000, 5001)], [(5001, 9999), (9999, n)]):
+        ops.pair_score_sample(h, W1, b1, W2, b2, bits, tab, seed=9, step=2, row_ranges=rng, out_upper=out, precision="bf16x3")
+    popcount = lambda t: int(np.unpackbits(t.cpu().numpy().view(np.uint8)).sum())
+    nd, edges = popcount(torch.bitwise_xor(exact, out)), popcount(exact)
+    print(f"bf16x3 vs f32 at n={n}: {nd} of {n * (n - 1) // 2} draws differ ({edges} edges sampled)")
+    assert edges > 1000 and nd <= 20
+
+
 @pytest.mark.parametrize("name", list(gu.CASES))
 def test_attribute_step_vs_reference_and_oracle(dev, name):
     ops = _ops()
