@@ -195,6 +195,38 @@ def secondary_rooflines(wl, model, bits, dev):
     ]
 
 
+BF16_MFMA_PEAK_TFLOPS = 2500.0                          # MI355X_MICROARCH.md: dense bf16 matrix peak
+
+
+def pair_precision_rooflines(model, x, oh, Y32, bits, T, dev):
+    """The opt-in bf16 paths of the pair kernel, measured alone on this step's node embeddings (outside the timed region;
+    the timed step and the headline roofline run the exact f32 kernel unless --pair-precision says otherwise).  `achieved`
+    counts the algorithmic FLOP of the reference's pair MLP (33,408 per pair), not the 3x MFMA work of the split."""
+    from graphmaker_amd import ops
+    n = model.num_nodes
+    tab_E, _ = model.step_tables(T)
+    t_float = torch.tensor([1.0], dtype=torch.float32, device=dev)
+    A_t = ops.adjacency_from_bitmap(bits, n)
+    h = model.graph_encoder.pred_E.gnn_encoder(t_float, oh, Y32, A_t)
+    W1, b1, W2, b2 = model.graph_encoder.pred_E.pair_params()
+    ws = ops.pair_workspace(dev)
+    out = torch.zeros_like(bits)
+    P = n * (n - 1) // 2
+    exact = ops.pair_score_sample(h, W1, b1, W2, b2, bits, tab_E, seed=5, step=T, workspace=ws).clone()
+    res = []
+    for prec in ("bf16x3", "bf16"):
+        ms = _time_ms(lambda: ops.pair_score_sample(h, W1, b1, W2, b2, bits, tab_E, seed=5, step=T, out_upper=out, workspace=ws,
+                                                    precision=prec), reps=5, warm=2)
+        differ = int(np.unpackbits(torch.bitwise_xor(out, exact).cpu().numpy().view(np.uint8)).sum())
+        tf = FLOP_PER_PAIR * P / (ms * 1e-3) / 1e12
+        res.append({"kernel": f"gm::k_pair_bf16 ({prec}, opt-in; not the timed step)", "bound": "mfma", "achieved": tf,
+                    "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "launch_ms": ms, "mfma_products_per_algorithmic_product": 3 if prec == "bf16x3" else 1,
+                    "draws_differing_from_f32": differ, "pairs": P})
+    ops.check_pair_workspace(ws)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,6 +237,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the stand-alone SpMM/GEMM timings and the full-sample run (profiling passes use this)")
     ap.add_argument("--cpu-rows", type=int, default=768)
+    ap.add_argument("--pair-precision", default="f32", choices=["f32", "bf16x3", "bf16"],
+                    help="f32 (default, exact; the headline) or the opt-in bf16 matrix-core paths of the pair kernel; the JSON "
+                         "line then says so in dtype and config")
     ap.add_argument("--force-plan", action="store_true",
                     help="run the sharded code path (ShardPlan + RCCL all-gathers) even with one rank: a rehearsal of N>1")
     ap.add_argument("--rehearse-world", type=int, default=0, metavar="G",
@@ -238,6 +273,7 @@ def main():
 
     from graphmaker_amd import ops
     model = build_model(wl, dev)
+    model.pair_precision = args.pair_precision
     n, T = wl["N"], wl["T"]
     Em = model.transition.E_marginal_host
     Y32 = ops.prior_Y(n, model.Y_marginal, seed=0)
@@ -317,7 +353,8 @@ def main():
             "metric": f"denoising steps/sec ({wl['name']} Sync step); pair-scores/sec in pair_scores_per_sec",
             "value": args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.pair_precision == "f32" else f"f32 (pair MLP hidden layer on {args.pair_precision} MFMA, opt-in)",
+            "data": "synthetic",
             "config": {"workload": f"{wl['name']} GraphMaker-Sync reverse step t=T: N={n} F={wl['F']} C={wl['C']} "
                                    f"hidden 512/64/{wl['gnn_E']['hidden_t']}/128, L=2; E_t = prior draw, nnz={nnz}; "
                                    f"all P={P} unordered pairs (N^2 equivalent {2 * P + n})",
@@ -342,6 +379,7 @@ def main():
             # (the two towers run on two streams beside each other: towers_wall is the time both take together)
             tower_ms = phases.get("towers_wall", phases.get("tower_E", float("nan")) + phases.get("tower_X", float("nan")))
             tf = tower_flop / (tower_ms * 1e-3) / 1e12
+            res["roofline_secondary"] += pair_precision_rooflines(model, x, oh, Y32, bits, T, dev)
             res["roofline_secondary"].append(
                 {"kernel": "both denoiser towers inside the step (all gm::k_linear launches + SpMM + LayerNorm + movers)",
                  "bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
