@@ -406,6 +406,9 @@ extern "C" int gm_pair_score_sample_ranges(int64_t n, int64_t hE, const float* h
                                            const float* tab, int nranges, const int64_t* row_ranges, const float* u,
                                            uint64_t seed, uint32_t step, uint32_t* out_upper, float* logits_dbg,
                                            float* post_dbg, void* workspace, gm_stream_t stream) {
+    if (hE != HE)   // any other width the reference accepts (model/gnn.py:204-231): the vector kernel of gm_pair_generic.hip
+        return gm_pair_generic_launch(n, hE, h, W1, b1, W2, b2, bits_t, wpr, tab, nranges, row_ranges, u, seed, step, out_upper,
+                                      logits_dbg, post_dbg, stream);
     PairArgs a;
     unsigned grid = 0;
     if (int rc = gm_build_pair_args(n, hE, h, W1, b1, W2, b2, bits_t, wpr, tab, nranges, row_ranges, u, seed, step, out_upper,

@@ -99,6 +99,11 @@ __device__ __forceinline__ float relu_bits(float x) {   // max(x, 0) for non-NaN
 
 // host: validate the arguments of gm_pair_score_sample_ranges and fill PairArgs + grid size (shared by both precisions).
 // Returns GM_OK with grid == 0 when there is nothing to do.
+int gm_pair_generic_launch(int64_t n, int64_t hE, const float* h, const float* W1, const float* b1, const float* W2,
+                           const float* b2, const uint32_t* bits_t, int64_t wpr, const float* tab, int nranges,
+                           const int64_t* row_ranges, const float* u, uint64_t seed, uint32_t step, uint32_t* out_upper,
+                           float* logits_dbg, float* post_dbg, gm_stream_t stream);
+
 static inline int gm_build_pair_args(int64_t n, int64_t hE, const float* h, const float* W1, const float* b1, const float* W2,
                                      const float* b2, const uint32_t* bits_t, int64_t wpr, const float* tab, int nranges,
                                      const int64_t* row_ranges, const float* u, uint64_t seed, uint32_t step,
@@ -106,7 +111,7 @@ static inline int gm_build_pair_args(int64_t n, int64_t hE, const float* h, cons
                                      gm_stream_t stream, gm::PairArgs& a, unsigned& grid) {
     using namespace gm;
     grid = 0;
-    GM_REQUIRE(hE == HE, "hidden_E=%lld is not supported: the pair kernel is built for hidden_E=128", (long long)hE);
+    GM_REQUIRE(hE == HE, "hidden_E=%lld: the matrix-core pair kernels are built for hidden_E=128", (long long)hE);
     GM_REQUIRE(n > 1 && n < (1ll << 31), "n out of range");
     GM_REQUIRE(wpr >= (n + 31) / 32 && wpr % 4 == 0, "bad wpr");
     GM_REQUIRE(h && W1 && b1 && W2 && b2 && bits_t && tab && out_upper && workspace, "null pointer");

@@ -11,7 +11,7 @@ import numpy as np
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
-# name -> config.  hidden_E stays 128 (every reference yaml uses 128; the HIP pair kernel is built for it).
+# name -> config.  hidden_E stays 128 (every reference yaml uses 128; other widths: tests/test_gpu_parity.py, against the oracle).
 CASES = {
     "sync_small": dict(variant="Sync", N=67, F=11, C=3, T=3, density=0.06, seed=11,
                        gnn_X=dict(hidden_t=8, hidden_X=32, hidden_Y=16, num_gnn_layers=2, dropout=0.0),

@@ -541,6 +541,39 @@ def test_pair_kernel_large_against_oracle_rows_and_sharding(dev):
     assert torch.equal(dense, dense.T) and int(dense.diagonal().sum()) == 0
 
 
+@pytest.mark.parametrize("hE,n", [(32, 333), (96, 130), (200, 257), (4, 64), (384, 70)])
+def test_pair_kernel_other_hidden_E(dev, hE, n):
+    """hidden_E != 128 (model/gnn.py:204-231 takes any width; the shipped configurations use 128): the vector kernel of
+    gm_pair_generic.hip behind the same entry point -- logits, posteriors and draws bit-exact against the oracle, row
+    ranges reproduce the whole, in-kernel Philox equals host-supplied uniforms."""
+    ops = _ops()
+    rs = np.random.RandomState(hE)
+    h = (rs.normal(size=(n, hE)) * 0.7).astype(np.float32)
+    W1 = (rs.normal(size=(hE, hE)) / np.sqrt(hE)).astype(np.float32)
+    b1 = (rs.normal(size=hE) * 0.1).astype(np.float32)
+    W2 = (rs.normal(size=(2, hE)) / np.sqrt(hE)).astype(np.float32)
+    b2 = np.array([0.5, -0.5], np.float32)
+    _, bits = random_sym_bits(n, 0.05, hE + 1)
+    tab = orc.posterior_table_E([0.95, 0.05], 0.58304191, 0.84701216, 0.49384356)
+    pair = orc.PairMLP(W1, b1, W2, b2)
+    args = [t_(x, dev) for x in (h, W1, b1, W2, b2)]
+    u = orc.uniform_E(7, 3, n)
+    up, lg, po = ops.pair_score_sample(*args, bits_t(bits, dev), tab, u=t_(u, dev), want_debug=True)
+    o_up, o_lg, o_po = orc.pair_score_sample(n, h, pair, bits, tab, u=u, want_debug=True)
+    np.testing.assert_array_equal(lg.cpu().numpy(), o_lg)
+    np.testing.assert_array_equal(po.cpu().numpy(), o_po)
+    np.testing.assert_array_equal(bits_np(ops.symmetrize_upper(up, n)), orc.symmetrize_upper(o_up, n))
+    up2 = ops.pair_score_sample(*args, bits_t(bits, dev), tab, seed=7, step=3)
+    assert torch.equal(ops.symmetrize_upper(up2, n), ops.symmetrize_upper(up, n))
+    out = torch.zeros_like(up)
+    a, b = n // 3, (2 * n) // 3 + 1
+    ops.pair_score_sample(*args, bits_t(bits, dev), tab, seed=7, step=3, out_upper=out, row_ranges=[(0, a), (a, a), (b, n)])
+    ops.pair_score_sample(*args, bits_t(bits, dev), tab, seed=7, step=3, out_upper=out, row_begin=a, row_end=b)
+    assert torch.equal(ops.symmetrize_upper(out, n), ops.symmetrize_upper(up, n))
+    with pytest.raises(Exception):
+        ops.pair_score_sample(*args, bits_t(bits, dev), tab, seed=7, step=3, precision="bf16x3")   # matrix-core paths: 128 only
+
+
 @pytest.mark.parametrize("n,density", [(67, 0.3), (777, 0.02), (2500, 0.004), (130, 0.0)])
 def test_edge_list_exchange_kernels(dev, n, density):
     """The multi-GPU exchange of the sampled edges: every rank's rows of the upper-triangle bitmap -> sorted (i<j) edge
@@ -621,14 +654,17 @@ def test_capped_csr_matches_exact_and_flags_overflow(dev):
         small.check()
 
 
-@pytest.mark.parametrize("N,F,C,density", [(2, 1, 1, 0.5), (3, 2, 2, 0.9), (33, 1, 5, 0.2), (65, 3, 1, 0.0), (129, 5, 3, 1.0)])
-def test_degenerate_sizes_whole_sample_bit_identical_to_oracle(dev, N, F, C, density):
+@pytest.mark.parametrize("N,F,C,density,hidden_E", [(2, 1, 1, 0.5, 128), (3, 2, 2, 0.9, 128), (33, 1, 5, 0.2, 128),
+                                                    (65, 3, 1, 0.0, 128), (129, 5, 3, 1.0, 128), (150, 4, 3, 0.1, 64),
+                                                    (70, 3, 2, 0.3, 20)])
+def test_degenerate_sizes_whole_sample_bit_identical_to_oracle(dev, N, F, C, density, hidden_E):
     """Smallest and ragged shapes (two nodes, one attribute, one class, an empty and a complete prior graph, sizes one
-    past a 32 / 64 / 128 boundary): the whole Sync sample equals the oracle's bit for bit."""
+    past a 32 / 64 / 128 boundary, a structure denoiser of another width than the shipped 128): the whole Sync sample
+    equals the oracle's bit for bit."""
     import graphmaker_amd as gm
     cfg = dict(variant="Sync", N=N, F=F, C=C, T=2, density=density, seed=100 + N,
                gnn_X=dict(hidden_t=4, hidden_X=8, hidden_Y=4, num_gnn_layers=1, dropout=0.0),
-               gnn_E=dict(hidden_t=4, hidden_X=8, hidden_Y=4, hidden_E=128, num_gnn_layers=1, dropout=0.0))
+               gnn_E=dict(hidden_t=4, hidden_X=8, hidden_Y=4, hidden_E=hidden_E, num_gnn_layers=1, dropout=0.0))
     Xm, Ym, Em = gu.marginals(cfg)
     sdX, sdE = gu.make_checkpoint(cfg, edge_bias=0.3, attr_bias=0.2)
     model = gm.ModelSync(T=cfg["T"], X_marginal=t_(Xm, dev), Y_marginal=t_(Ym, dev), E_marginal=t_(Em, dev),
