@@ -119,6 +119,40 @@ __device__ __forceinline__ void softmax2_diff(float d, float& q0, float& q1) {
     q0 = pos ? small : r;
     q1 = pos ? r : small;
 }
+// The same function, same bits for every finite d, in fewer vector-ALU instructions (in the pair kernels each one costs
+// matrix-pipe time): -|d| through source modifiers, the clamp as one max, and 1/s for s in [1, 2] as the compiler's own
+// division sequence without its scaling and fix-up steps (which are the identity in that range).
+__device__ __forceinline__ float rcp_1to2(float s) {
+    float r = __builtin_amdgcn_rcpf(s);
+    float e = __builtin_fmaf(-s, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    float q = r;
+    e = __builtin_fmaf(-s, q, 1.0f);
+    q = __builtin_fmaf(e, r, q);
+    e = __builtin_fmaf(-s, q, 1.0f);
+    return __builtin_fmaf(e, r, q);
+}
+__device__ __forceinline__ void softmax2_diff_lean(float d, float& q0, float& q1) {
+    float x = __builtin_fmaxf(-__builtin_fabsf(d), -80.0f);
+    float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693359375f, x);
+    r = __builtin_fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    float r2 = r * r;
+    float y = __builtin_fmaf(p, r2, r) + 1.0f;
+    const float e = __builtin_ldexpf(y, (int)n);
+    const float s = 1.0f + e;
+    const float rs = rcp_1to2(s);
+    const float small = e * rs;
+    const bool pos = d > 0.0f;
+    q0 = pos ? small : rs;
+    q1 = pos ? rs : small;
+}
 // posterior from the table tab[(i*2+k)*2+e] (model/diffusion.py:351-406 for a one-hot Z_t = e)
 __device__ __forceinline__ void posterior2(const float* tab, int e, float q0, float q1, float& p0, float& p1) {
     float a0 = q0 * tab[0 + e];

@@ -85,23 +85,23 @@ __device__ __forceinline__ void stage_store_half(float* hIs, float* hJs, int gt,
     }
 }
 
+typedef float floatx2 __attribute__((ext_vector_type(2)));
 struct Frag {
     float4 w[4];
     float4 hi, ha, hb;
-    float z0[4], z1[4];   // h_i * h_j for the fragment's four k-steps, strip 0 / strip 1
+    floatx2 z0[2], z1[2];   // h_i * h_j for the fragment's four k-steps, strip 0 / strip 1 (pairs: one v_pk_mul_f32 each)
 };
 
 // z for a fragment whose LDS reads have landed.  Done one half-iteration ahead of the MFMAs that consume it, so the
 // multiplies (and the VALU->MFMA operand wait states) run in the shadow of the previous block's last MFMAs.
 __device__ __forceinline__ void prep_frag(Frag& f) {
-    const float hiv[4] = {f.hi.x, f.hi.y, f.hi.z, f.hi.w};
-    const float hav[4] = {f.ha.x, f.ha.y, f.ha.z, f.ha.w};
-    const float hbv[4] = {f.hb.x, f.hb.y, f.hb.z, f.hb.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        f.z0[e] = hiv[e] * hav[e];
-        f.z1[e] = hiv[e] * hbv[e];
-    }
+    // spelled out: left to itself hipcc splits these into eight v_mul_f32 inside the unrolled loop
+    const floatx2 hi01 = {f.hi.x, f.hi.y}, hi23 = {f.hi.z, f.hi.w};
+    const floatx2 ha01 = {f.ha.x, f.ha.y}, ha23 = {f.ha.z, f.ha.w}, hb01 = {f.hb.x, f.hb.y}, hb23 = {f.hb.z, f.hb.w};
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(f.z0[0]) : "v"(hi01), "v"(ha01));
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(f.z0[1]) : "v"(hi23), "v"(ha23));
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(f.z1[0]) : "v"(hi01), "v"(hb01));
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(f.z1[1]) : "v"(hi23), "v"(hb23));
 }
 
 __device__ __forceinline__ void load_frag(Frag& f, const float* wrow, const float* hirow, const float* hjrow, int q) {
@@ -116,7 +116,7 @@ __device__ __forceinline__ void load_frag(Frag& f, const float* wrow, const floa
 __device__ __forceinline__ void mma_frag(floatx16 (&acc)[2][4], const Frag& f) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const float z0 = f.z0[e], z1 = f.z1[e];
+        const float z0 = f.z0[e >> 1][e & 1], z1 = f.z1[e >> 1][e & 1];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const float wv_ = e == 0 ? f.w[mt].x : e == 1 ? f.w[mt].y : e == 2 ? f.w[mt].z : f.w[mt].w;
@@ -130,7 +130,7 @@ __device__ __forceinline__ void mma_frag(floatx16 (&acc)[2][4], const Frag& f) {
 // reference's LinkPredictor output); the draws and posteriors come from the same logit-difference path in both.
 template <bool DBG>
 __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const PairArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[(HE + 2 * TILE) * LDR + HE + 3 * HE + 32];
+    __shared__ __attribute__((aligned(16))) float lds[(HE + 2 * TILE) * LDR + HE + 3 * HE + 32 + HE + 8 * 256];
     float* W1s = lds;
     float* hIs = W1s + HE * LDR;
     float* hJs = hIs + TILE * LDR;
@@ -140,6 +140,8 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
     int* tile_s = reinterpret_cast<int*>(W2s + 2 * HE);   // tile_s[0..1]: ring of queue items, [2]: items published
     int* stg_s = tile_s + 4;                       // stg_s[w], w < 4: tiles wave w has staged
     int* turn_s = tile_s + 8;                      // turn_s[w]: MFMA row-units wave w has issued so far (hand-off flags)
+    float* b1s2 = W2s + 2 * HE + 32;               // a second copy of b1: strip 1's accumulators are read from it directly
+    uint32_t* rng_s = reinterpret_cast<uint32_t*>(b1s2 + HE);   // [wave][4 row-units][64 columns] Philox words
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -152,7 +154,7 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
         const int o = q >> 5, c4 = q & 31;
         put_split(W1s + o * LDR, c4, *reinterpret_cast<const float4*>(a.W1 + o * HE + 4 * c4));
     }
-    if (tid < HE) b1s[tid] = a.b1[tid];
+    if (tid < HE) { b1s[tid] = a.b1[tid]; b1s2[tid] = a.b1[tid]; }
     if (tid < HE) dws[tid] = a.W2[HE + tid] - a.W2[tid];
     if (tid < 2 * HE) W2s[tid] = a.W2[tid];
     const float b20 = a.b2[0], b21 = a.b2[1];
@@ -177,7 +179,7 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
     volatile int* my_turn = turn_s + wv;
     volatile int* partner_turn = turn_s + (wv ^ 4);
 #ifdef GM_PAIR_STAMP   // diagnostic build: cycle sums of wave 0 / wave 4 of block 0 -> post_dbg (never in the product)
-    unsigned long long st_mma = 0, st_epi = 0, st_phase = 0, st_n = 0, st_init = 0;
+    unsigned long long st_mma = 0, st_epi = 0, st_phase = 0, st_n = 0, st_init = 0, st_wait = 0;
 #define STAMP() __builtin_readcyclecounter()
     const unsigned long long st_c0 = STAMP(), st_r0 = wall_clock64();   // shader cycles vs the constant 100 MHz clock
 #endif
@@ -201,72 +203,86 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
 #endif
             const int il = wv + 8 * u;
             const int64_t i = i0 + il;
+            const bool active = i < row_end && i < a.n;      // wave-uniform
+            const float* wrow = W1s + l31 * LDR + 64 * half;
+            const float* hirow = hIs + il * LDR + 64 * half;
+            const float* hjrow = hJs + l31 * LDR + 64 * half;
+            Frag f0, f1;
+            // Everything the first MFMA needs is fetched BEFORE the wave asks for its turn -- b1 into the accumulators, the
+            // first fragment read and multiplied -- under the partner's MFMA run, so that the matrix pipe changes hands
+            // without waiting for LDS round trips (the stamps showed ~2.6k idle cycles per hand-over otherwise).
+            if (active) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        // every vector-ALU instruction on this SIMD costs matrix-pipe time: the second
+                        // strip reads its own LDS copy of b1 straight into its accumulators instead of 64 v_mov
+                        const float4 bv = *reinterpret_cast<const float4*>(b1s + mt * 32 + 8 * g + 4 * half);
+                        const float4 bw = *reinterpret_cast<const float4*>(b1s2 + mt * 32 + 8 * g + 4 * half);
+                        acc[0][mt][4 * g + 0] = bv.x; acc[0][mt][4 * g + 1] = bv.y;
+                        acc[0][mt][4 * g + 2] = bv.z; acc[0][mt][4 * g + 3] = bv.w;
+                        acc[1][mt][4 * g + 0] = bw.x; acc[1][mt][4 * g + 1] = bw.y;
+                        acc[1][mt][4 * g + 2] = bw.z; acc[1][mt][4 * g + 3] = bw.w;
+                    }
+                load_frag(f0, wrow, hirow, hjrow, 0);
+                prep_frag(f0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef GM_PAIR_STAMP
+            st_init += STAMP() - ph0;
+            const unsigned long long wt0 = STAMP();
+#endif
             {   // wait for the partner: group 0 needs its partner's unit (units_done-1), group 1 its partner's unit units_done
                 const int need = units_done + grp;
                 // bounded: the order is a speed matter only, results never depend on it
                 for (int spin = 0; spin < (1 << 16) && *partner_turn < need; ++spin) __builtin_amdgcn_s_sleep(1);
             }
             __builtin_amdgcn_sched_barrier(0);
-            {
-                if (i < row_end && i < a.n) {                    // wave-uniform
 #ifdef GM_PAIR_STAMP
-                    const unsigned long long m0 = STAMP();
+            st_wait += STAMP() - wt0;
 #endif
+            if (active) {
+#ifdef GM_PAIR_STAMP
+                const unsigned long long m1 = STAMP();
+#endif
+#ifndef GM_PAIR_PRIO
+#define GM_PAIR_PRIO 1
+#endif
+                if (GM_PAIR_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+                if (GM_PAIR_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+                // fragments for k-block q+1 are read from LDS while the 32 MFMAs of block q run; fully unrolled: every
+                // LDS offset is an immediate, no address arithmetic between the MFMAs
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const float4 bv = *reinterpret_cast<const float4*>(b1s + mt * 32 + 8 * g + 4 * half);
-                            acc[0][mt][4 * g + 0] = bv.x; acc[0][mt][4 * g + 1] = bv.y;
-                            acc[0][mt][4 * g + 2] = bv.z; acc[0][mt][4 * g + 3] = bv.w;
-                            acc[1][mt][4 * g + 0] = bv.x; acc[1][mt][4 * g + 1] = bv.y;
-                            acc[1][mt][4 * g + 2] = bv.z; acc[1][mt][4 * g + 3] = bv.w;
-                        }
-                    const float* wrow = W1s + l31 * LDR + 64 * half;
-                    const float* hirow = hIs + il * LDR + 64 * half;
-                    const float* hjrow = hJs + l31 * LDR + 64 * half;
-                    // fragments for k-block q+1 are read from LDS while the 32 MFMAs of block q run
-                    Frag f0, f1;
-#ifdef GM_PAIR_STAMP
-                    const unsigned long long m1 = STAMP();
-                    st_init += m1 - m0;
-#endif
-                    load_frag(f0, wrow, hirow, hjrow, 0);
-                    prep_frag(f0);
-                    // the multiplying wave outranks its partner's epilogue at the SIMD's issue arbiter (+0.6%)
-                    __builtin_amdgcn_s_setprio(1);
-#pragma unroll 1
-                    for (int q = 0; q < HE / 8; q += 2) {
-#ifdef GM_PAIR_NO_LDS   // exploration only
-                        if (q == 0)
-#endif
-                        load_frag(f1, wrow, hirow, hjrow, q + 1);
-                        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMAs it overlaps
-                        mma_frag(acc, f0);
-                        __builtin_amdgcn_sched_barrier(0);
-                        prep_frag(f1);
-                        __builtin_amdgcn_sched_barrier(0);
-#ifndef GM_PAIR_NO_LDS
-                        load_frag(f0, wrow, hirow, hjrow, (q + 2) & (HE / 8 - 1));
-#endif
-                        __builtin_amdgcn_sched_barrier(0);
-                        mma_frag(acc, f1);
-                        __builtin_amdgcn_sched_barrier(0);
-                        prep_frag(f0);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    __builtin_amdgcn_s_setprio(0);
-#ifdef GM_PAIR_STAMP
-                    asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[1][3]));
-                    st_mma += STAMP() - m1;
-                    st_n += 1;
-#endif
+                for (int q = 0; q < HE / 8; q += 2) {
+                    load_frag(f1, wrow, hirow, hjrow, q + 1);
+                    __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMAs it overlaps
+                    mma_frag(acc, f0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    prep_frag(f1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (q + 2 < HE / 8) load_frag(f0, wrow, hirow, hjrow, q + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_frag(acc, f1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (q + 2 < HE / 8) prep_frag(f0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+                if (GM_PAIR_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+                if (GM_PAIR_PRIO == 2) __builtin_amdgcn_s_setprio(2);
+#ifdef GM_PAIR_STAMP
+                asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[1][3]));
+                st_mma += STAMP() - m1;
+                st_n += 1;
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
             ++units_done;
             if (lane == 0) *my_turn = units_done;
             __builtin_amdgcn_sched_barrier(0);
+#ifdef GM_PAIR_STAMP
+            const unsigned long long ep0 = STAMP();
+#endif
             {
 #ifdef GM_PAIR_NO_EPILOGUE   // exploration only: results are garbage
 #pragma unroll
@@ -330,16 +346,31 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
                     if (wi < a.wpr) etw = a.bits_t[i * a.wpr + wi];
                     const bool e = (etw >> l31) & 1u;
                     float q0, q1;
-                    softmax2_diff(D, q0, q1);
+                    softmax2_diff_lean(D, q0, q1);
                     const float a0 = q0 * (e ? a.tab[1] : a.tab[0]);
                     const float c0 = q1 * (e ? a.tab[5] : a.tab[4]);
                     const float a1 = q0 * (e ? a.tab[3] : a.tab[2]);
                     const float c1 = q1 * (e ? a.tab[7] : a.tab[6]);
                     const float p0 = a0 + c0, p1 = a1 + c1;
-                    const int64_t rank = i * (2 * a.n - i - 1) / 2 + (j - i - 1);
+                    // rank-indexed arrays (host uniforms, logits, posteriors) exist in the DBG instantiation only
+                    const int64_t rank = DBG ? i * (2 * a.n - i - 1) / 2 + (j - i - 1) : 0;
+                    const int unit = u;
                     float u;
-                    if (a.u) u = valid ? a.u[rank] : 1.0f;
-                    else u = u_pair(a.seed, a.step, (uint32_t)i, (uint32_t)j);
+                    if (DBG && a.u) u = valid ? a.u[rank] : 1.0f;
+                    else {
+                        // One Philox block serves 4 consecutive columns, so per row-unit only 16 of 64 lanes would do
+                        // distinct work: every fourth unit the wave computes the blocks of its next FOUR units instead
+                        // (lane = 16 * unit + block) and parks the words in LDS; a wave reads back only its own words.
+                        uint32_t* mine = rng_s + wv * 256;
+                        const int ph = (unit - ub) & 3;
+                        if (ph == 0) {
+                            const uint32_t ir = (uint32_t)(i0 + wv + 8 * (unit + (lane >> 4)));
+                            const u32x4 o = philox4x32_10((uint32_t)(j0 >> 2) + (uint32_t)(lane & 15), ir, a.step, STREAM_E,
+                                                          (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+                            *reinterpret_cast<uint4*>(mine + 4 * lane) = make_uint4(o.v[0], o.v[1], o.v[2], o.v[3]);
+                        }
+                        u = u01(mine[ph * 64 + lane]);
+                    }
                     const bool bit = valid && draw2(u, p0, p1);
                     const unsigned long long m = __ballot(bit);
                     if (lane == 0) {
@@ -348,14 +379,16 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
                         if (w0i + 1 < a.wpr) a.out_upper[i * a.wpr + w0i + 1] = (uint32_t)(m >> 32);
                     }
 #ifndef GM_PAIR_STAMP   // the diagnostic build reuses post_dbg for its stamps
-                    if (valid) {
-                        if (DBG && a.logits_dbg) { a.logits_dbg[2 * rank] = L0; a.logits_dbg[2 * rank + 1] = L1; }
+                    if (DBG && valid) {
+                        if (a.logits_dbg) { a.logits_dbg[2 * rank] = L0; a.logits_dbg[2 * rank + 1] = L1; }
                         if (a.post_dbg) { a.post_dbg[2 * rank] = p0; a.post_dbg[2 * rank + 1] = p1; }
                     }
 #endif
                 }
             }
 #ifdef GM_PAIR_STAMP
+            asm volatile("s_nop 0" ::: "memory");
+            st_epi += STAMP() - ep0;
             st_phase += STAMP() - ph0;
 #endif
         }
@@ -392,7 +425,7 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
     if (blockIdx.x == 0 && lane == 0 && (wv == 0 || wv == 4) && a.post_dbg) {
         float* o = a.post_dbg + 8 * grp;
         o[0] = (float)st_mma; o[1] = (float)st_epi; o[2] = (float)st_phase; o[3] = (float)st_n; o[4] = (float)st_init;
-        o[5] = (float)(STAMP() - st_c0); o[6] = (float)(wall_clock64() - st_r0);
+        o[5] = (float)(STAMP() - st_c0); o[6] = (float)(wall_clock64() - st_r0); o[7] = (float)st_wait;
     }
 #endif
 }
@@ -416,7 +449,12 @@ extern "C" int gm_pair_score_sample_ranges(int64_t n, int64_t hE, const float* h
         return rc;
     if (grid == 0) return GM_OK;
     hipStream_t s = as_stream(stream);
-    if (logits_dbg) hipLaunchKernelGGL(k_pair_score_sample<true>, dim3(grid), dim3(PAIR_THREADS), 0, s, a);
+#ifdef GM_PAIR_STAMP   // the diagnostic build passes its stamp buffer as post_dbg and must time the product instantiation
+    const bool dbg = logits_dbg != nullptr;
+#else
+    const bool dbg = logits_dbg || post_dbg || u;
+#endif
+    if (dbg) hipLaunchKernelGGL(k_pair_score_sample<true>, dim3(grid), dim3(PAIR_THREADS), 0, s, a);
     else hipLaunchKernelGGL(k_pair_score_sample<false>, dim3(grid), dim3(PAIR_THREADS), 0, s, a);
     GM_LAUNCH_CHECK();
     return GM_OK;

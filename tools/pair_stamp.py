@@ -22,7 +22,7 @@ for _ in range(2):
 torch.cuda.synchronize()
 d = dbg.cpu().numpy()
 for g_ in (0, 1):
-    mma, epi, phase, cnt, init, cyc, rt = d[8 * g_: 8 * g_ + 7]
+    mma, epi, phase, cnt, init, cyc, rt, wait = d[8 * g_: 8 * g_ + 8]
     print(f"group {g_}: workgroup 0 lived {cyc:.0f} shader cycles = {rt / 100:.1f} us of the 100 MHz clock -> {cyc / rt * 100:.0f} MHz average")
-    print(f"group {g_}: units {cnt:.0f}  mma loop {mma / cnt:.0f} cyc/unit  acc init {init / cnt:.0f}  epilogue-phase(incl barrier wait) "
-          f"{epi / cnt:.0f}  phase total {phase / (2 * cnt):.0f} cyc/phase")
+    print(f"group {g_}: units {cnt:.0f}  per unit: wait for the turn {wait / cnt:.0f}  acc init {init / cnt:.0f}  mma loop {mma / cnt:.0f}  "
+          f"epilogue {epi / cnt:.0f}  whole {phase / cnt:.0f} cycles (two waves share a SIMD: {phase / (2 * cnt):.0f} per unit of SIMD time)")
