@@ -176,8 +176,8 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
         stage_tile(a.h, a.n, i0, j0, hIs, hJs, tid);
     }
     __syncthreads();
-    volatile int* my_turn = turn_s + wv;
-    volatile int* partner_turn = turn_s + (wv ^ 4);
+    lds_flag* my_turn = as_lds_flag(turn_s + wv);
+    lds_flag* partner_turn = as_lds_flag(turn_s + (wv ^ 4));
 #ifdef GM_PAIR_STAMP   // diagnostic build: cycle sums of wave 0 / wave 4 of block 0 -> post_dbg (never in the product)
     unsigned long long st_mma = 0, st_epi = 0, st_phase = 0, st_n = 0, st_init = 0, st_wait = 0;
 #define STAMP() __builtin_readcyclecounter()
@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
         decode_tile(a, tile, i0, j0, tj, row_end);
 
         // the h rows of item number `seq` are in LDS once waves 0-3 have all staged `seq` tiles
-        stalled |= !wait_all_ge(stg_s, 4, seq, lane);
+        stalled |= !wait_all_ge(as_lds_flag(stg_s), 4, seq, lane);
 
         floatx16 acc[2][4];
         // 8 row-units per wave and tile.  The two waves of a SIMD (w, w+4) alternate on the matrix pipe: group 0 runs
@@ -251,6 +251,8 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
 #endif
                 if (GM_PAIR_PRIO == 1) __builtin_amdgcn_s_setprio(1);
                 if (GM_PAIR_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+                if (GM_PAIR_PRIO == 3 && grp == 0) __builtin_amdgcn_s_setprio(1);
+                if (GM_PAIR_PRIO == 4) __builtin_amdgcn_s_setprio(1);
                 // fragments for k-block q+1 are read from LDS while the 32 MFMAs of block q run; fully unrolled: every
                 // LDS offset is an immediate, no address arithmetic between the MFMAs
 #pragma unroll
@@ -270,6 +272,8 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
                 }
                 if (GM_PAIR_PRIO == 1) __builtin_amdgcn_s_setprio(0);
                 if (GM_PAIR_PRIO == 2) __builtin_amdgcn_s_setprio(2);
+                if (GM_PAIR_PRIO == 3 && grp == 0) __builtin_amdgcn_s_setprio(0);
+                if (GM_PAIR_PRIO == 4) { if (grp == 0) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
 #ifdef GM_PAIR_STAMP
                 asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[1][3]));
                 st_mma += STAMP() - m1;
@@ -402,11 +406,11 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
             if (lane == 0) {
                 tile_s[seq & 1] = (int)atomicAdd(a.counter, 1u);   // slot last read before item seq-1 began
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                *reinterpret_cast<volatile int*>(tile_s + 2) = seq;
+                *as_lds_flag(tile_s + 2) = seq;
             }
         }
-        stalled |= !wait_all_ge(tile_s + 2, 1, seq, lane);
-        t = reinterpret_cast<volatile int*>(tile_s)[seq & 1];
+        stalled |= !wait_all_ge(as_lds_flag(tile_s + 2), 1, seq, lane);
+        t = as_lds_flag(tile_s)[seq & 1];
         if (grp == 0 && t < a.nitems) {
             int64_t ni0, nj0, nre, ntile;
             int ntj_, nub, nue;
@@ -414,10 +418,10 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
             decode_tile(a, ntile, ni0, nj0, ntj_, nre);
             float4 v[16];
             stage_load_half(a.h, a.n, ni0, nj0, tid, v);
-            stalled |= !wait_all_ge(turn_s, 8, units_done, lane);
+            stalled |= !wait_all_ge(as_lds_flag(turn_s), 8, units_done, lane);
             stage_store_half(hIs, hJs, tid, v);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) *reinterpret_cast<volatile int*>(stg_s + wv) = seq;
+            if (lane == 0) *as_lds_flag(stg_s + wv) = seq;
         }
     }
     if (stalled && lane == 0) atomicOr(a.stall, 1u);

@@ -76,9 +76,15 @@ __device__ __forceinline__ void decode_item(const PairArgs& a, int64_t it, int64
     }
 }
 
+// Flags in LDS are read and written through LDS-address-space pointers: through a generic `volatile int*` hipcc emits FLAT
+// loads and stores (sc0 sc1, each followed by s_waitcnt vmcnt(0)), which take the long way round and make the publishing wave
+// wait for its outstanding global stores as well.
+typedef __attribute__((address_space(3))) volatile int lds_flag;
+__device__ __forceinline__ lds_flag* as_lds_flag(int* p) { return (lds_flag*)p; }
+
 // Wait until the first `cnt` ints at `flags` are all >= need (every lane returns the same answer).  These waits guard
 // LDS contents, so they are long; a wave that gives up reports it through PairArgs::stall instead of hanging the GPU.
-__device__ __forceinline__ bool wait_all_ge(volatile int* flags, int cnt, int need, int lane) {
+__device__ __forceinline__ bool wait_all_ge(lds_flag* flags, int cnt, int need, int lane) {
     for (int spin = 0; spin < (1 << 22); ++spin) {
         const int v = lane < cnt ? flags[lane] : 0x7fffffff;
         if (__all(v >= need)) {

@@ -10,7 +10,7 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 // mode: 0 MFMA only; 1 + one ds_read_b128 per 3 MFMAs (same wave); 2 + two ds_read_b64 per 3 MFMAs; 3 + one ds_read_b32 per 3;
 //       4 + ds_read_b128 per 3 MFMAs, all lanes of a half-wave read the same address (broadcast);
 //       5: waves 4-7 (second wave of each SIMD) do the ds_read_b128 stream, waves 0-3 MFMA only;  6: waves 4-7 do v_mul stream
-//       7: + one ds_read_b128 per MFMA (same wave)
+//       7: + one ds_read_b128 per MFMA (same wave);  8 / 9: LDS float atomics (max, then min with return) from the same / a second wave
 template <int MODE>
 __global__ void __launch_bounds__(512)
 k_mix(int iters, float* out) {
@@ -35,6 +35,8 @@ k_mix(int iters, float* out) {
                     asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8" : "=v"(*(double*)&r1), "=v"(*(double*)&r2) : "v"(addr));
                 } else if (MODE == 3 && k % 3 == 0) {
                     asm volatile("ds_read_b32 %0, %1" : "=v"(r0.x) : "v"(addr));
+                } else if (MODE == 8) {   // ReLU through the LDS atomic unit: max into a zeroed word, then min-with-return resets it
+                    asm volatile("ds_max_f32 %1, %2\n\tds_min_rtn_f32 %0, %1, %3" : "=v"(r0.x) : "v"(addr), "v"(y), "v"(0.0f));
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -55,6 +57,17 @@ k_mix(int iters, float* out) {
                 acc += r0.x;
                 __builtin_amdgcn_s_sleep(2);
             }
+        }
+        if (acc == 12345.678f) out[threadIdx.x] = acc;
+    } else if (MODE == 9) {
+        float r = 0, acc = 0;
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int k = 0; k < 24; ++k) {
+                asm volatile("ds_max_f32 %1, %2\n\tds_min_rtn_f32 %0, %1, %3" : "=v"(r) : "v"(addr), "v"(acc + 1.0f), "v"(0.0f));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            acc += r * 1e-30f;
         }
         if (acc == 12345.678f) out[threadIdx.x] = acc;
     } else if (MODE == 6) {
@@ -95,6 +108,8 @@ int main() {
     run<3>("+ 1 ds_read_b32 per 3 MFMAs, same wave", iters, out);
     run<4>("+ 1 ds_read_b128 per 3 MFMAs, same wave, one address per half-wave (broadcast)", iters, out);
     run<7>("+ 1 ds_read_b128 per MFMA, same wave", iters, out);
+    run<8>("+ 1 ds_max_f32 + 1 ds_min_rtn_f32 per MFMA, same wave", iters, out);
+    run<9>("MFMA wave + a second wave issuing ds_max_f32 + ds_min_rtn_f32 pairs (1 pair per MFMA)", iters, out);
     run<5>("MFMA wave + a second wave on the SIMD reading ds_read_b128 in a loop", iters, out);
     run<6>("MFMA wave + a second wave on the SIMD running v_mul_f32 back to back", iters, out);
     return 0;
