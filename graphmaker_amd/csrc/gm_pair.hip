@@ -130,7 +130,7 @@ __device__ __forceinline__ void mma_frag(floatx16 (&acc)[2][4], const Frag& f) {
 // reference's LinkPredictor output); the draws and posteriors come from the same logit-difference path in both.
 template <bool DBG>
 __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const PairArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[(HE + 2 * TILE) * LDR + HE + 3 * HE + 32 + HE + 8 * 256];
+    __shared__ __attribute__((aligned(16))) float lds[(HE + 2 * TILE) * LDR + HE + 3 * HE + 32 + HE + 8 * 256 + 8];
     float* W1s = lds;
     float* hIs = W1s + HE * LDR;
     float* hJs = hIs + TILE * LDR;
@@ -142,6 +142,7 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
     int* turn_s = tile_s + 8;                      // turn_s[w]: MFMA row-units wave w has issued so far (hand-off flags)
     float* b1s2 = W2s + 2 * HE + 32;               // a second copy of b1: strip 1's accumulators are read from it directly
     uint32_t* rng_s = reinterpret_cast<uint32_t*>(b1s2 + HE);   // [wave][4 row-units][64 columns] Philox words
+    float* tab_s = reinterpret_cast<float*>(rng_s + 8 * 256);   // posterior table as two rows [E_t bit][4]: one ds_read_b128 per pair
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -161,10 +162,13 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
     const float db = b21 - b20;
 
     if (tid == 0) { tile_s[0] = (int)atomicAdd(a.counter, 1u); tile_s[2] = 0; }
+    if (tid < 8) tab_s[tid] = a.tab[((tid & 3) == 0 ? 0 : (tid & 3) == 1 ? 4 : (tid & 3) == 2 ? 2 : 6) + (tid >> 2)];
     if (tid < 8) turn_s[tid] = 0;
     if (tid < 4) stg_s[tid] = 0;
     __syncthreads();
-    int64_t t = tile_s[0];
+    // the queue item is wave-uniform: in a scalar register, the tile decoding and every address derived from it run on the
+    // scalar unit (vector-ALU instructions cost matrix-pipe time)
+    int64_t t = __builtin_amdgcn_readfirstlane(tile_s[0]);
     int seq = 0;                                   // queue items this workgroup has finished (same in every wave)
     int units_done = 0;                            // row-units this wave has multiplied (same count in every wave)
     bool stalled = false;
@@ -331,10 +335,11 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
                     }
                     // Half-wave h finishes strip h: it keeps its own partial of that strip and receives the partner's
                     // (lane ^ 32) partial of the same strip, so softmax / posterior / draw run once per pair.
-                    const float recv = __shfl_xor(half ? part[0] : part[1], 32);
-                    const float own = half ? part[1] : part[0];
-                    // (hidden units with bit 2 clear) + (bit 2 set), then the bias difference: the oracle's order
-                    const float D = ((half ? recv : own) + (half ? own : recv)) + db;
+                    // One v_permlane32_swap: afterwards lanes 0-31 hold (own strip-0 partial, the upper half's strip-0 partial)
+                    // and lanes 32-63 (the lower half's strip-1 partial, own strip-1 partial), i.e. in both halves
+                    // (hidden units with bit 2 clear) + (bit 2 set); then the bias difference: the oracle's order
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(part[0]), __float_as_uint(part[1]), false, false);
+                    const float D = (__uint_as_float(sw[0]) + __uint_as_float(sw[1])) + db;
                     float L0 = 0.0f, L1 = 0.0f;
                     if (DBG) {
                         const float r0 = __shfl_xor(half ? dbg0[0] : dbg0[1], 32), r1 = __shfl_xor(half ? dbg1[0] : dbg1[1], 32);
@@ -344,17 +349,21 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
                     }
 
                     const int64_t j = j0 + lane;                       // lanes 0-31: strip 0, lanes 32-63: strip 1
-                    const int64_t wi = 2 * (int64_t)tj + half;
-                    const bool valid = (j > i) && (j < a.n);
-                    uint32_t etw = 0;
-                    if (wi < a.wpr) etw = a.bits_t[i * a.wpr + wi];
-                    const bool e = (etw >> l31) & 1u;
+                    const bool valid = ((int)j0 + lane > (int)i) && ((int)j0 + lane < (int)a.n);   // n < 2^31 (host check)
+                    // words 2 tj and 2 tj + 1 of row i: below wpr for every tile (wpr is a multiple of 4 and >= ceil(n/32), host
+                    // check), 8-byte aligned, wave-uniform -> one scalar load through the constant address space
+                    typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
+                    typedef __attribute__((address_space(4))) const uintx2 const_uintx2;
+                    const uintx2 et2 = *(const_uintx2*)(a.bits_t + i * a.wpr + 2 * (int64_t)tj);
+                    const uint32_t etw = half ? et2[1] : et2[0];
+                    const int e = (etw >> l31) & 1u;
                     float q0, q1;
                     softmax2_diff_lean(D, q0, q1);
-                    const float a0 = q0 * (e ? a.tab[1] : a.tab[0]);
-                    const float c0 = q1 * (e ? a.tab[5] : a.tab[4]);
-                    const float a1 = q0 * (e ? a.tab[3] : a.tab[2]);
-                    const float c1 = q1 * (e ? a.tab[7] : a.tab[6]);
+                    const float4 tb = *reinterpret_cast<const float4*>(tab_s + 4 * e);   // tab[e], tab[4+e], tab[2+e], tab[6+e]
+                    const float a0 = q0 * tb.x;
+                    const float c0 = q1 * tb.y;
+                    const float a1 = q0 * tb.z;
+                    const float c1 = q1 * tb.w;
                     const float p0 = a0 + c0, p1 = a1 + c1;
                     // rank-indexed arrays (host uniforms, logits, posteriors) exist in the DBG instantiation only
                     const int64_t rank = DBG ? i * (2 * a.n - i - 1) / 2 + (j - i - 1) : 0;
@@ -377,11 +386,7 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
                     }
                     const bool bit = valid && draw2(u, p0, p1);
                     const unsigned long long m = __ballot(bit);
-                    if (lane == 0) {
-                        const int64_t w0i = 2 * (int64_t)tj;
-                        if (w0i < a.wpr) a.out_upper[i * a.wpr + w0i] = (uint32_t)m;
-                        if (w0i + 1 < a.wpr) a.out_upper[i * a.wpr + w0i + 1] = (uint32_t)(m >> 32);
-                    }
+                    if (lane == 0) *reinterpret_cast<unsigned long long*>(a.out_upper + i * a.wpr + 2 * (int64_t)tj) = m;
 #ifndef GM_PAIR_STAMP   // the diagnostic build reuses post_dbg for its stamps
                     if (DBG && valid) {
                         if (a.logits_dbg) { a.logits_dbg[2 * rank] = L0; a.logits_dbg[2 * rank + 1] = L1; }
@@ -410,7 +415,7 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
             }
         }
         stalled |= !wait_all_ge(as_lds_flag(tile_s + 2), 1, seq, lane);
-        t = as_lds_flag(tile_s)[seq & 1];
+        t = __builtin_amdgcn_readfirstlane(as_lds_flag(tile_s)[seq & 1]);
         if (grp == 0 && t < a.nitems) {
             int64_t ni0, nj0, nre, ntile;
             int ntj_, nub, nue;
