@@ -85,7 +85,6 @@ __device__ __forceinline__ void stage_store_half(float* hIs, float* hJs, int gt,
     }
 }
 
-typedef float floatx2 __attribute__((ext_vector_type(2)));
 struct Frag {
     float4 w[4];
     float4 hi, ha, hb;
@@ -291,109 +290,10 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
 #ifdef GM_PAIR_STAMP
             const unsigned long long ep0 = STAMP();
 #endif
-            {
-#ifdef GM_PAIR_NO_EPILOGUE   // exploration only: results are garbage
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) asm volatile("" ::"v"(acc[s][mt]));
-                if (false) {
-#else
-                if (i < row_end && i < a.n) {
-#endif
-                    // ---- second layer as a logit difference d = l1 - l0 = (W2[1] - W2[0]) . relu(hid) + (b2[1] - b2[0])
-                    // (softmax over two classes needs nothing else): in-lane dot over this lane's 64 hidden units, both strips
-                    float part[2];
-                    float dbg0[2] = {0.0f, 0.0f}, dbg1[2] = {0.0f, 0.0f};
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        float dd = 0.0f;
-#pragma unroll
-                        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                            for (int g = 0; g < 4; ++g) {
-                                const int ob = mt * 32 + 8 * g + 4 * half;
-                                const float4 wd = *reinterpret_cast<const float4*>(dws + ob);
-                                const float wdv[4] = {wd.x, wd.y, wd.z, wd.w};
-#pragma unroll
-                                for (int r4 = 0; r4 < 4; ++r4)
-                                    dd = __builtin_fmaf(relu_bits(acc[s][mt][4 * g + r4]), wdv[r4], dd);
-                                if (DBG) {
-                                    const float4 w0 = *reinterpret_cast<const float4*>(W2s + ob);
-                                    const float4 w1 = *reinterpret_cast<const float4*>(W2s + HE + ob);
-                                    const float w0v[4] = {w0.x, w0.y, w0.z, w0.w};
-                                    const float w1v[4] = {w1.x, w1.y, w1.z, w1.w};
-#pragma unroll
-                                    for (int r4 = 0; r4 < 4; ++r4) {
-                                        const float hid = relu_bits(acc[s][mt][4 * g + r4]);
-                                        dbg0[s] = __builtin_fmaf(hid, w0v[r4], dbg0[s]);
-                                        dbg1[s] = __builtin_fmaf(hid, w1v[r4], dbg1[s]);
-                                    }
-                                }
-                            }
-                        part[s] = dd;
-                    }
-                    // Half-wave h finishes strip h: it keeps its own partial of that strip and receives the partner's
-                    // (lane ^ 32) partial of the same strip, so softmax / posterior / draw run once per pair.
-                    // One v_permlane32_swap: afterwards lanes 0-31 hold (own strip-0 partial, the upper half's strip-0 partial)
-                    // and lanes 32-63 (the lower half's strip-1 partial, own strip-1 partial), i.e. in both halves
-                    // (hidden units with bit 2 clear) + (bit 2 set); then the bias difference: the oracle's order
-                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(part[0]), __float_as_uint(part[1]), false, false);
-                    const float D = (__uint_as_float(sw[0]) + __uint_as_float(sw[1])) + db;
-                    float L0 = 0.0f, L1 = 0.0f;
-                    if (DBG) {
-                        const float r0 = __shfl_xor(half ? dbg0[0] : dbg0[1], 32), r1 = __shfl_xor(half ? dbg1[0] : dbg1[1], 32);
-                        const float o0 = half ? dbg0[1] : dbg0[0], o1 = half ? dbg1[1] : dbg1[0];
-                        L0 = ((half ? r0 : o0) + (half ? o0 : r0)) + b20;
-                        L1 = ((half ? r1 : o1) + (half ? o1 : r1)) + b21;
-                    }
-
-                    const int64_t j = j0 + lane;                       // lanes 0-31: strip 0, lanes 32-63: strip 1
-                    const bool valid = ((int)j0 + lane > (int)i) && ((int)j0 + lane < (int)a.n);   // n < 2^31 (host check)
-                    // words 2 tj and 2 tj + 1 of row i: below wpr for every tile (wpr is a multiple of 4 and >= ceil(n/32), host
-                    // check), 8-byte aligned, wave-uniform -> one scalar load through the constant address space
-                    typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
-                    typedef __attribute__((address_space(4))) const uintx2 const_uintx2;
-                    const uintx2 et2 = *(const_uintx2*)(a.bits_t + i * a.wpr + 2 * (int64_t)tj);
-                    const uint32_t etw = half ? et2[1] : et2[0];
-                    const int e = (etw >> l31) & 1u;
-                    float q0, q1;
-                    softmax2_diff_lean(D, q0, q1);
-                    const float4 tb = *reinterpret_cast<const float4*>(tab_s + 4 * e);   // tab[e], tab[4+e], tab[2+e], tab[6+e]
-                    const float a0 = q0 * tb.x;
-                    const float c0 = q1 * tb.y;
-                    const float a1 = q0 * tb.z;
-                    const float c1 = q1 * tb.w;
-                    const float p0 = a0 + c0, p1 = a1 + c1;
-                    // rank-indexed arrays (host uniforms, logits, posteriors) exist in the DBG instantiation only
-                    const int64_t rank = DBG ? i * (2 * a.n - i - 1) / 2 + (j - i - 1) : 0;
-                    const int unit = u;
-                    float u;
-                    if (DBG && a.u) u = valid ? a.u[rank] : 1.0f;
-                    else {
-                        // One Philox block serves 4 consecutive columns, so per row-unit only 16 of 64 lanes would do
-                        // distinct work: every fourth unit the wave computes the blocks of its next FOUR units instead
-                        // (lane = 16 * unit + block) and parks the words in LDS; a wave reads back only its own words.
-                        uint32_t* mine = rng_s + wv * 256;
-                        const int ph = (unit - ub) & 3;
-                        if (ph == 0) {
-                            const uint32_t ir = (uint32_t)(i0 + wv + 8 * (unit + (lane >> 4)));
-                            const u32x4 o = philox4x32_10((uint32_t)(j0 >> 2) + (uint32_t)(lane & 15), ir, a.step, STREAM_E,
-                                                          (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
-                            *reinterpret_cast<uint4*>(mine + 4 * lane) = make_uint4(o.v[0], o.v[1], o.v[2], o.v[3]);
-                        }
-                        u = u01(mine[ph * 64 + lane]);
-                    }
-                    const bool bit = valid && draw2(u, p0, p1);
-                    const unsigned long long m = __ballot(bit);
-                    if (lane == 0) *reinterpret_cast<unsigned long long*>(a.out_upper + i * a.wpr + 2 * (int64_t)tj) = m;
-#ifndef GM_PAIR_STAMP   // the diagnostic build reuses post_dbg for its stamps
-                    if (DBG && valid) {
-                        if (a.logits_dbg) { a.logits_dbg[2 * rank] = L0; a.logits_dbg[2 * rank + 1] = L1; }
-                        if (a.post_dbg) { a.post_dbg[2 * rank] = p0; a.post_dbg[2 * rank + 1] = p1; }
-                    }
-#endif
-                }
+            if (active) {
+                EpiCtx ec;
+                ec.dws = dws; ec.W2s = W2s; ec.tab_s = tab_s; ec.rng_mine = rng_s + wv * 256; ec.db = db; ec.b20 = b20; ec.b21 = b21;
+                pair_epilogue<DBG>(a, ec, acc, i, i0, j0, tj, u, ub, wv, lane);
             }
 #ifdef GM_PAIR_STAMP
             asm volatile("s_nop 0" ::: "memory");

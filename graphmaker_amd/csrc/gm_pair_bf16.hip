@@ -57,6 +57,8 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_bf16(const PairArgs a)
     __shared__ __attribute__((aligned(16))) float hJs[TILE * LDHF];
     __shared__ __attribute__((aligned(16))) float b1s[HE], dws[HE], W2s[2 * HE];
     __shared__ int tile_s[2];
+    __shared__ __attribute__((aligned(16))) uint32_t rng_s[8 * 256];   // [wave][4 row-units][64 columns] Philox words
+    __shared__ __attribute__((aligned(16))) float tab_s[8];            // posterior table, rows [E_t bit][4]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -79,11 +81,12 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_bf16(const PairArgs a)
     if (tid < HE) b1s[tid] = a.b1[tid];
     if (tid < HE) dws[tid] = a.W2[HE + tid] - a.W2[tid];
     if (tid < 2 * HE) W2s[tid] = a.W2[tid];
+    if (tid < 8) tab_s[tid] = a.tab[((tid & 3) == 0 ? 0 : (tid & 3) == 1 ? 4 : (tid & 3) == 2 ? 2 : 6) + (tid >> 2)];
     const float b20 = a.b2[0], b21 = a.b2[1];
     const float db = b21 - b20;
     if (tid == 0) tile_s[0] = (int)atomicAdd(a.counter, 1u);
     __syncthreads();
-    int64_t t = tile_s[0];
+    int64_t t = __builtin_amdgcn_readfirstlane(tile_s[0]);   // wave-uniform: tile decoding and addresses on the scalar unit
     int seq = 0;
 
     while (t < a.nitems) {
@@ -146,86 +149,13 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_bf16(const PairArgs a)
                     acc[1][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, zh1, acc[1][mt], 0, 0, 0);
                 }
             }
-            {
-            // ---- second layer as a logit difference d = l1 - l0 = (W2[1] - W2[0]) . relu(hid) + (b2[1] - b2[0])
-            // (softmax over two classes needs nothing else): in-lane dot over this lane's 64 hidden units, both strips
-            float part[2];
-            float dbg0[2] = {0.0f, 0.0f}, dbg1[2] = {0.0f, 0.0f};
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                float dd = 0.0f;
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int ob = mt * 32 + 8 * g + 4 * half;
-                        const float4 wd = *reinterpret_cast<const float4*>(dws + ob);
-                        const float wdv[4] = {wd.x, wd.y, wd.z, wd.w};
-#pragma unroll
-                        for (int r4 = 0; r4 < 4; ++r4)
-                            dd = __builtin_fmaf(relu_bits(acc[s][mt][4 * g + r4]), wdv[r4], dd);
-                        if (DBG) {
-                            const float4 w0 = *reinterpret_cast<const float4*>(W2s + ob);
-                            const float4 w1 = *reinterpret_cast<const float4*>(W2s + HE + ob);
-                            const float w0v[4] = {w0.x, w0.y, w0.z, w0.w};
-                            const float w1v[4] = {w1.x, w1.y, w1.z, w1.w};
-#pragma unroll
-                            for (int r4 = 0; r4 < 4; ++r4) {
-                                const float hid = relu_bits(acc[s][mt][4 * g + r4]);
-                                dbg0[s] = __builtin_fmaf(hid, w0v[r4], dbg0[s]);
-                                dbg1[s] = __builtin_fmaf(hid, w1v[r4], dbg1[s]);
-                            }
-                        }
-                    }
-                part[s] = dd;
-            }
-            // Half-wave h finishes strip h: it keeps its own partial of that strip and receives the partner's
-            // (lane ^ 32) partial of the same strip, so softmax / posterior / draw run once per pair.
-            const float recv = __shfl_xor(half ? part[0] : part[1], 32);
-            const float own = half ? part[1] : part[0];
-            // (hidden units with bit 2 clear) + (bit 2 set), then the bias difference: the oracle's order
-            const float D = ((half ? recv : own) + (half ? own : recv)) + db;
-            float L0 = 0.0f, L1 = 0.0f;
-            if (DBG) {
-                const float r0 = __shfl_xor(half ? dbg0[0] : dbg0[1], 32), r1 = __shfl_xor(half ? dbg1[0] : dbg1[1], 32);
-                const float o0 = half ? dbg0[1] : dbg0[0], o1 = half ? dbg1[1] : dbg1[0];
-                L0 = ((half ? r0 : o0) + (half ? o0 : r0)) + b20;
-                L1 = ((half ? r1 : o1) + (half ? o1 : r1)) + b21;
-            }
-
-            const int64_t j = j0 + lane;                       // lanes 0-31: strip 0, lanes 32-63: strip 1
-            const int64_t wi = 2 * (int64_t)tj + half;
-            const bool valid = (j > i) && (j < a.n);
-            uint32_t etw = 0;
-            if (wi < a.wpr) etw = a.bits_t[i * a.wpr + wi];
-            const bool e = (etw >> l31) & 1u;
-            float q0, q1;
-            softmax2_diff(D, q0, q1);
-            const float a0 = q0 * (e ? a.tab[1] : a.tab[0]);
-            const float c0 = q1 * (e ? a.tab[5] : a.tab[4]);
-            const float a1 = q0 * (e ? a.tab[3] : a.tab[2]);
-            const float c1 = q1 * (e ? a.tab[7] : a.tab[6]);
-            const float p0 = a0 + c0, p1 = a1 + c1;
-            const int64_t rank = i * (2 * a.n - i - 1) / 2 + (j - i - 1);
-            float u;
-            if (a.u) u = valid ? a.u[rank] : 1.0f;
-            else u = u_pair(a.seed, a.step, (uint32_t)i, (uint32_t)j);
-            const bool bit = valid && draw2(u, p0, p1);
-            const unsigned long long m = __ballot(bit);
-            if (lane == 0) {
-                const int64_t w0i = 2 * (int64_t)tj;
-                if (w0i < a.wpr) a.out_upper[i * a.wpr + w0i] = (uint32_t)m;
-                if (w0i + 1 < a.wpr) a.out_upper[i * a.wpr + w0i + 1] = (uint32_t)(m >> 32);
-            }
-                    if (valid) {
-                        if (DBG && a.logits_dbg) { a.logits_dbg[2 * rank] = L0; a.logits_dbg[2 * rank + 1] = L1; }
-                        if (a.post_dbg) { a.post_dbg[2 * rank] = p0; a.post_dbg[2 * rank + 1] = p1; }
-                    }
-            }
+            EpiCtx ec;
+            ec.dws = dws; ec.W2s = W2s; ec.tab_s = tab_s; ec.rng_mine = rng_s + wv * 256; ec.db = db; ec.b20 = b20; ec.b21 = b21;
+            pair_epilogue<DBG>(a, ec, acc, i, i0, j0, tj, u, ub, wv, lane);
         }
         __syncthreads();                       // every wave is done with this tile's h rows (and tile_s has the next item)
         ++seq;
-        t = tile_s[seq & 1];
+        t = __builtin_amdgcn_readfirstlane(tile_s[seq & 1]);
     }
 }
 
@@ -247,11 +177,12 @@ extern "C" int gm_pair_score_sample_bf16(int64_t n, int64_t hE, const float* h, 
     if (grid == 0) return GM_OK;
     hipStream_t s = as_stream(stream);
     const dim3 g(grid), b(PAIR_THREADS);
+    const bool dbg = logits_dbg || post_dbg || u;    // rank-indexed arrays exist in the DBG instantiation only
     if (nprod == 3) {
-        if (logits_dbg) hipLaunchKernelGGL((k_pair_bf16<3, true>), g, b, 0, s, a);
+        if (dbg) hipLaunchKernelGGL((k_pair_bf16<3, true>), g, b, 0, s, a);
         else hipLaunchKernelGGL((k_pair_bf16<3, false>), g, b, 0, s, a);
     } else {
-        if (logits_dbg) hipLaunchKernelGGL((k_pair_bf16<1, true>), g, b, 0, s, a);
+        if (dbg) hipLaunchKernelGGL((k_pair_bf16<1, true>), g, b, 0, s, a);
         else hipLaunchKernelGGL((k_pair_bf16<1, false>), g, b, 0, s, a);
     }
     GM_LAUNCH_CHECK();

@@ -100,6 +100,117 @@ __device__ __forceinline__ float relu_bits(float x) {   // max(x, 0) for non-NaN
     return __int_as_float(max(__float_as_int(x), 0));
 }
 
+// ---- what follows the 128x128 product of a row-unit in both matrix-core kernels (f32: gm_pair.hip, bf16: gm_pair_bf16.hip):
+// second layer, softmax, posterior, draw, bitmap word.  acc[strip][o-tile] is the 32x32 MFMA accumulator layout: lane
+// (l31 = column = pair, half) holds hidden units o = 32 mt + 8 g + 4 half + r in register 4 g + r of tile mt.
+struct EpiCtx {
+    const float* dws;       // LDS: W2[1] - W2[0]
+    const float* W2s;       // LDS: both rows of W2 (DBG only)
+    const float* tab_s;     // LDS: posterior table as two rows [E_t bit][4] = tab[e], tab[4+e], tab[2+e], tab[6+e]
+    uint32_t* rng_mine;     // LDS: this wave's 256 Philox words, [4 row-units][64 columns]
+    float db, b20, b21;     // b2[1] - b2[0], b2[0], b2[1]
+};
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+
+template <bool DBG>
+__device__ __forceinline__ void pair_epilogue(const PairArgs& a, const EpiCtx& c, floatx16 (&acc)[2][4], int64_t i, int64_t i0,
+                                              int64_t j0, int tj, int unit, int ub, int wv, int lane) {
+    const int l31 = lane & 31, half = lane >> 5;
+    // ---- second layer as a logit difference d = l1 - l0 = (W2[1] - W2[0]) . relu(hid) + (b2[1] - b2[0])
+    // (softmax over two classes needs nothing else): in-lane dot over this lane's 64 hidden units, both strips
+    // Even and odd hidden units sit in adjacent accumulator registers, so one v_pk_fma_f32 advances two chains
+    // (oracle: C[h][p] over ascending o with ((o>>2)&1)==h, (o&1)==p): 64 packed FMAs per strip instead of 128.
+    float part[2];
+    float dbg0[2] = {0.0f, 0.0f}, dbg1[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        floatx2 dd = {0.0f, 0.0f};
+        floatx2 d0 = {0.0f, 0.0f}, d1 = {0.0f, 0.0f};
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ob = mt * 32 + 8 * g + 4 * half;
+                const float4 wd = *reinterpret_cast<const float4*>(c.dws + ob);
+                const floatx2 wlo = {wd.x, wd.y}, whi = {wd.z, wd.w};
+                const floatx2 xlo = {relu_bits(acc[s][mt][4 * g + 0]), relu_bits(acc[s][mt][4 * g + 1])};
+                const floatx2 xhi = {relu_bits(acc[s][mt][4 * g + 2]), relu_bits(acc[s][mt][4 * g + 3])};
+                asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(dd) : "v"(xlo), "v"(wlo));
+                asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(dd) : "v"(xhi), "v"(whi));
+                if (DBG) {
+                    const float4 w0 = *reinterpret_cast<const float4*>(c.W2s + ob);
+                    const float4 w1 = *reinterpret_cast<const float4*>(c.W2s + HE + ob);
+                    const float w0v[4] = {w0.x, w0.y, w0.z, w0.w};
+                    const float w1v[4] = {w1.x, w1.y, w1.z, w1.w};
+                    const float xv[4] = {xlo[0], xlo[1], xhi[0], xhi[1]};
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        d0[r4 & 1] = __builtin_fmaf(xv[r4], w0v[r4], d0[r4 & 1]);
+                        d1[r4 & 1] = __builtin_fmaf(xv[r4], w1v[r4], d1[r4 & 1]);
+                    }
+                }
+            }
+        part[s] = dd[0] + dd[1];
+        if (DBG) { dbg0[s] = d0[0] + d0[1]; dbg1[s] = d1[0] + d1[1]; }
+    }
+    // One v_permlane32_swap: afterwards lanes 0-31 hold (own strip-0 partial, the upper half's strip-0 partial)
+    // and lanes 32-63 (the lower half's strip-1 partial, own strip-1 partial), i.e. in both halves
+    // (hidden units with bit 2 clear) + (bit 2 set); then the bias difference: the oracle's order
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(part[0]), __float_as_uint(part[1]), false, false);
+    const float D = (__uint_as_float(sw[0]) + __uint_as_float(sw[1])) + c.db;
+    float L0 = 0.0f, L1 = 0.0f;
+    if (DBG) {
+        const float r0 = __shfl_xor(half ? dbg0[0] : dbg0[1], 32), r1 = __shfl_xor(half ? dbg1[0] : dbg1[1], 32);
+        const float o0 = half ? dbg0[1] : dbg0[0], o1 = half ? dbg1[1] : dbg1[0];
+        L0 = ((half ? r0 : o0) + (half ? o0 : r0)) + c.b20;
+        L1 = ((half ? r1 : o1) + (half ? o1 : r1)) + c.b21;
+    }
+
+    const int64_t j = j0 + lane;                       // lanes 0-31: strip 0, lanes 32-63: strip 1
+    const bool valid = ((int)j0 + lane > (int)i) && ((int)j0 + lane < (int)a.n);   // n < 2^31 (host check)
+    // words 2 tj and 2 tj + 1 of row i: below wpr for every tile (wpr is a multiple of 4 and >= ceil(n/32), host
+    // check), 8-byte aligned, wave-uniform -> one scalar load through the constant address space
+    typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(4))) const uintx2 const_uintx2;
+    const uintx2 et2 = *(const_uintx2*)(a.bits_t + i * a.wpr + 2 * (int64_t)tj);
+    const uint32_t etw = half ? et2[1] : et2[0];
+    const int e = (etw >> l31) & 1u;
+    float q0, q1;
+    softmax2_diff_lean(D, q0, q1);
+    const float4 tb = *reinterpret_cast<const float4*>(c.tab_s + 4 * e);   // tab[e], tab[4+e], tab[2+e], tab[6+e]
+    const float a0 = q0 * tb.x;
+    const float c0 = q1 * tb.y;
+    const float a1 = q0 * tb.z;
+    const float c1 = q1 * tb.w;
+    const float p0 = a0 + c0, p1 = a1 + c1;
+    // rank-indexed arrays (host uniforms, logits, posteriors) exist in the DBG instantiation only
+    const int64_t rank = DBG ? i * (2 * a.n - i - 1) / 2 + (j - i - 1) : 0;
+    float u;
+    if (DBG && a.u) u = valid ? a.u[rank] : 1.0f;
+    else {
+        // One Philox block serves 4 consecutive columns, so per row-unit only 16 of 64 lanes would do
+        // distinct work: every fourth unit the wave computes the blocks of its next FOUR units instead
+        // (lane = 16 * unit + block) and parks the words in LDS; a wave reads back only its own words.
+        uint32_t* mine = c.rng_mine;
+        const int ph = (unit - ub) & 3;
+        if (ph == 0) {
+            const uint32_t ir = (uint32_t)(i0 + wv + 8 * (unit + (lane >> 4)));
+            const u32x4 o = philox4x32_10((uint32_t)(j0 >> 2) + (uint32_t)(lane & 15), ir, a.step, STREAM_E,
+                                          (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+            *reinterpret_cast<uint4*>(mine + 4 * lane) = make_uint4(o.v[0], o.v[1], o.v[2], o.v[3]);
+        }
+        u = u01(mine[ph * 64 + lane]);
+    }
+    const bool bit = valid && draw2(u, p0, p1);
+    const unsigned long long m = __ballot(bit);
+    if (lane == 0) *reinterpret_cast<unsigned long long*>(a.out_upper + i * a.wpr + 2 * (int64_t)tj) = m;
+#ifndef GM_PAIR_STAMP   // the diagnostic build reuses post_dbg for its stamps
+    if (DBG && valid) {
+        if (a.logits_dbg) { a.logits_dbg[2 * rank] = L0; a.logits_dbg[2 * rank + 1] = L1; }
+        if (a.post_dbg) { a.post_dbg[2 * rank] = p0; a.post_dbg[2 * rank + 1] = p1; }
+    }
+#endif
+}
 
 }  // namespace gm
 

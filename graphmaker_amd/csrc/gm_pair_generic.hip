@@ -1,7 +1,7 @@
 // gm_pair_generic.hip -- the all-pairs structure denoiser for hidden_E != 128 (model/gnn.py:204-231 takes any hidden_E; every
 // shipped configuration uses 128, which runs the MFMA kernel of gm_pair.hip).  Same loop (model/diffusion.py:444-470), same
 // arithmetic orders as oracle gmo_pair_score_sample -- hidden[o] = fmaf chain over ascending k from b1[o]; logit difference =
-// two fmaf chains on W2[1]-W2[0] over ascending o split by bit 2 of o, summed, + (b2[1]-b2[0]) -- on the vector ALU:
+// four fmaf chains on W2[1]-W2[0] over ascending o split by bits 2 and 0 of o, summed pairwise, + (b2[1]-b2[0]) -- on the vector ALU:
 // one wave per (row i, 64 consecutive columns j), one pair per lane.  The wave's z = h_i * h_j values sit in LDS as
 // z[k][lane]; W1 rows are wave-uniform, so they come through the scalar cache.  VALU-bound (f32 vector peak = f32 MFMA peak on
 // this chip, but every FMA also needs its z operand from LDS): a correct path for unusual configurations, not a tuned one.
@@ -67,7 +67,7 @@ k_pair_generic(const GenArgs a) {
     const float* hi_row = a.h + i * hE;
     const float* hj_row = a.h + (j < a.n ? j : a.n - 1) * hE;
     for (int k = 0; k < hE; ++k) z[k * 64 + lane] = hi_row[k] * hj_row[k];   // a lane reads back only what it wrote
-    float s0 = 0.0f, s1 = 0.0f, t00 = 0.0f, t01 = 0.0f, t10 = 0.0f, t11 = 0.0f;
+    float sd[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, t0[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, t1[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
     const bool dbg = a.logits_dbg != nullptr;
     for (int o = 0; o < hE; ++o) {
         const float* w = a.W1 + (int64_t)o * hE;        // wave-uniform row
@@ -75,13 +75,20 @@ k_pair_generic(const GenArgs a) {
         for (int k = 0; k < hE; ++k) acc = __builtin_fmaf(z[k * 64 + lane], w[k], acc);
         const float hid = acc > 0.0f ? acc : 0.0f;
         const float dw = a.W2[hE + o] - a.W2[o];
-        if ((o >> 2) & 1) s1 = __builtin_fmaf(hid, dw, s1); else s0 = __builtin_fmaf(hid, dw, s0);
-        if (dbg) {
-            if ((o >> 2) & 1) { t01 = __builtin_fmaf(hid, a.W2[o], t01); t11 = __builtin_fmaf(hid, a.W2[hE + o], t11); }
-            else { t00 = __builtin_fmaf(hid, a.W2[o], t00); t10 = __builtin_fmaf(hid, a.W2[hE + o], t10); }
-        }
+        const int hs = (o >> 2) & 1, par = o & 1;                 // wave-uniform
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+                if (hs == x && par == y) {
+                    sd[x][y] = __builtin_fmaf(hid, dw, sd[x][y]);
+                    if (dbg) {
+                        t0[x][y] = __builtin_fmaf(hid, a.W2[o], t0[x][y]);
+                        t1[x][y] = __builtin_fmaf(hid, a.W2[hE + o], t1[x][y]);
+                    }
+                }
     }
-    const float D = (s0 + s1) + (a.b2[1] - a.b2[0]);
+    const float D = ((sd[0][0] + sd[0][1]) + (sd[1][0] + sd[1][1])) + (a.b2[1] - a.b2[0]);
     const int64_t wi = j >> 5;
     uint32_t etw = 0;
     if (wi < a.wpr) etw = a.bits_t[i * a.wpr + wi];
@@ -106,8 +113,8 @@ k_pair_generic(const GenArgs a) {
     }
     if (valid) {
         if (dbg) {
-            a.logits_dbg[2 * rank] = (t00 + t01) + a.b2[0];
-            a.logits_dbg[2 * rank + 1] = (t10 + t11) + a.b2[1];
+            a.logits_dbg[2 * rank] = ((t0[0][0] + t0[0][1]) + (t0[1][0] + t0[1][1])) + a.b2[0];
+            a.logits_dbg[2 * rank + 1] = ((t1[0][0] + t1[0][1]) + (t1[1][0] + t1[1][1])) + a.b2[1];
         }
         if (a.post_dbg) { a.post_dbg[2 * rank] = p0; a.post_dbg[2 * rank + 1] = p1; }
     }

@@ -579,8 +579,9 @@ void gmo_onehot_linear(int64_t n, int64_t F, int64_t H, const float* X_one_hot, 
 /* ------------------------------------------------------------------ structure denoiser */
 /* model/gnn.py:246-248  logit = W2 relu(W1 (h_i * h_j) + b1) + b2.
  * Orders: hidden[o] = fmaf chain over k ascending starting from b1[o];
- *         logit[c]  = (S0 + S1) + b2[c] with S_h = fmaf chain over ascending o with ((o>>2)&1)==h
- *         (the split a 32x32 MFMA accumulator tile gives the two half-waves). */
+ *         logit[c]  = (S0 + S1) + b2[c],  S_h = C[h][0] + C[h][1],  C[h][p] = fmaf chain over ascending o with
+ *         ((o>>2)&1)==h and (o&1)==p  (h: the split a 32x32 MFMA accumulator tile gives the two half-waves; p: even / odd
+ *         hidden units sit in adjacent accumulator registers, so one packed FMA advances both chains). */
 void gmo_pair_logits(int64_t hE, const float* hi, const float* hj, const float* W1, const float* b1,
                      const float* W2, const float* b2, float logit[2]) {
     float z[1024], hid[1024];
@@ -592,12 +593,12 @@ void gmo_pair_logits(int64_t hE, const float* hi, const float* hj, const float* 
         hid[o] = acc > 0.0f ? acc : 0.0f;
     }
     for (int c = 0; c < 2; ++c) {
-        float s[2] = {0.0f, 0.0f};
+        float s[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
         for (int64_t o = 0; o < hE; ++o) {
-            int hsel = (int)((o >> 2) & 1);
-            s[hsel] = fmaf(hid[o], W2[c * hE + o], s[hsel]);
+            int hsel = (int)((o >> 2) & 1), par = (int)(o & 1);
+            s[hsel][par] = fmaf(hid[o], W2[c * hE + o], s[hsel][par]);
         }
-        logit[c] = (s[0] + s[1]) + b2[c];
+        logit[c] = ((s[0][0] + s[0][1]) + (s[1][0] + s[1][1])) + b2[c];
     }
 }
 
@@ -654,15 +655,15 @@ void gmo_pair_score_sample(int64_t n, int64_t hE, const float* h, const float* W
             }
             for (int b = 0; b < nj; ++b) {
                 const int64_t j = jb0 + b;
-                /* logit difference d = l1 - l0 on dw = W2[1] - W2[0]: (S0 + S1) + (b2[1] - b2[0]), S_h = fmaf chain over
-                 * ascending o with ((o>>2)&1)==h (the split a 32x32 MFMA accumulator tile gives the two half-waves) */
-                float s[2] = {0.0f, 0.0f};
+                /* logit difference d = l1 - l0 on dw = W2[1] - W2[0]: (S0 + S1) + (b2[1] - b2[0]), S_h = C[h][0] + C[h][1],
+                 * C[h][p] = fmaf chain over ascending o with ((o>>2)&1)==h, (o&1)==p (see gmo_pair_logits) */
+                float s[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
                 for (int64_t o = 0; o < hE; ++o) {
                     float r = hid[b][o] > 0.0f ? hid[b][o] : 0.0f;
-                    int hsel = (int)((o >> 2) & 1);
-                    s[hsel] = fmaf(r, dw[o], s[hsel]);
+                    int hsel = (int)((o >> 2) & 1), par = (int)(o & 1);
+                    s[hsel][par] = fmaf(r, dw[o], s[hsel][par]);
                 }
-                const float d = (s[0] + s[1]) + db;
+                const float d = ((s[0][0] + s[0][1]) + (s[1][0] + s[1][1])) + db;
                 float q0, q1, p0, p1;
                 gmo_softmax2_diff(d, &q0, &q1);                                  /* diffusion.py:457 */
                 int e_t = (int)((bits_t[i * wpr + (j >> 5)] >> (j & 31)) & 1u);  /* diffusion.py:460-462 */
@@ -672,13 +673,13 @@ void gmo_pair_score_sample(int64_t n, int64_t hE, const float* h, const float* W
                 if (draw2(u, p0, p1)) orow[j >> 5] |= 1u << (j & 31);            /* diffusion.py:421 */
                 if (logits_dbg) {      /* both logits (model/gnn.py:248), for comparison with the reference only */
                     for (int c = 0; c < 2; ++c) {
-                        float t[2] = {0.0f, 0.0f};
+                        float t[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
                         for (int64_t o = 0; o < hE; ++o) {
                             float rl = hid[b][o] > 0.0f ? hid[b][o] : 0.0f;
-                            int hsel = (int)((o >> 2) & 1);
-                            t[hsel] = fmaf(rl, W2[c * hE + o], t[hsel]);
+                            int hsel = (int)((o >> 2) & 1), par = (int)(o & 1);
+                            t[hsel][par] = fmaf(rl, W2[c * hE + o], t[hsel][par]);
                         }
-                        logits_dbg[2 * r + c] = (t[0] + t[1]) + b2[c];
+                        logits_dbg[2 * r + c] = ((t[0][0] + t[0][1]) + (t[1][0] + t[1][1])) + b2[c];
                     }
                 }
                 if (post_dbg) { post_dbg[2 * r] = p0; post_dbg[2 * r + 1] = p1; }
