@@ -38,6 +38,8 @@ int launch_gather_rows(int64_t n, int w, const int32_t* idx, const float* table,
 int launch_broadcast_row(int64_t n, int w, const float* row, float* dst, int64_t ldd, hipStream_t s);
 int launch_spmm_mean_rows(int64_t n, int64_t hn, const int32_t* rowptr, const int32_t* colidx, const float* H, int64_t ldh,
                           int64_t d, float* out, int64_t ldo, hipStream_t s);
+int launch_spmm_mean_two(int64_t n, const int32_t* rowptr, const int32_t* colidx, const float* HX, int64_t dX, const float* HY,
+                         int64_t dY, int64_t ldh, float* out, int64_t ldo, hipStream_t s);
 int launch_copy2d(int64_t n, int w, const float* src, int64_t lds_, float* dst, int64_t ldd, hipStream_t s);
 int launch_time_embed(int ht, const float* t, const float* W0, const float* b0, const float* W1, const float* b1, int64_t rows,
                       float* dst1, int64_t ld1, float* dst2, int64_t ld2, hipStream_t s);

@@ -45,7 +45,8 @@ struct SpmmSched {
 template <bool TRANSPOSED, int TPR, int CH>
 __global__ void __launch_bounds__(256)
 k_spmm_seg(int64_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, const float* __restrict__ H,
-           int64_t ldh, int nchunks, float* __restrict__ out, int64_t ldo, const SpmmSched sc) {
+           const float* __restrict__ H2, int split, int64_t ldh, int nchunks, float* __restrict__ out, int64_t ldo,
+           const SpmmSched sc) {
     constexpr int NG = 256 / TPR;                       // groups per workgroup
     constexpr int SW = TPR * CH;                        // chunks per slab
     constexpr int NB = TPR == 8 ? 8 : 4;                // neighbours in flight per lane
@@ -81,10 +82,12 @@ k_spmm_seg(int64_t n, const int32_t* __restrict__ rowptr, const int32_t* __restr
     const int tid = threadIdx.x, g = tid / TPR, l = tid % TPR;
     int cc[CH];                                           // this lane's float4 chunks
     bool on[CH];
-#pragma unroll
+    const float* src[CH];                                 // chunk cc of the operand: H below `split`, H2 from there on
+#pragma unroll                                            // (the towers' [h_X | h_Y] are two column ranges of one buffer)
     for (int c = 0; c < CH; ++c) {
         cc[c] = slab * SW + l + TPR * c;
         on[c] = cc[c] < nchunks;
+        src[c] = cc[c] < split ? H + 4 * cc[c] : H2 + 4 * (cc[c] - split);
     }
 
     // ---- the block's item list: lanes 0..31 of wave 0 take a row each, two in-wave prefix sums place its items and slots
@@ -174,7 +177,7 @@ k_spmm_seg(int64_t n, const int32_t* __restrict__ rowptr, const int32_t* __restr
                     w[q] = TRANSPOSED ? (in ? w_s[g][k + q] : 0.0f) : inv_row;
 #pragma unroll
                     for (int c = 0; c < CH; ++c)
-                        v[q][c] = (in && on[c]) ? *reinterpret_cast<const float4*>(H + (int64_t)j * ldh + 4 * cc[c])
+                        v[q][c] = (in && on[c]) ? *reinterpret_cast<const float4*>(src[c] + (int64_t)j * ldh)
                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
@@ -375,16 +378,25 @@ int launch_copy2d(int64_t n, int w, const float* src, int64_t lds_, float* dst, 
 using namespace gm;
 
 // n output rows (rowptr[0..n]); the dense operand H may have more rows (a rank aggregates only its node block)
+// H2 / d2: optional second column range of the operand (same row stride), appended to the d columns of H in the output
 template <bool TRANSPOSED>
 static int launch_spmm(int64_t n, const int32_t* rowptr, const int32_t* colidx, const float* H, int64_t ldh, int64_t d,
-                       float* out, int64_t ldo, hipStream_t s, int64_t hn = 0) {
+                       float* out, int64_t ldo, hipStream_t s, int64_t hn = 0, const float* H2 = nullptr, int64_t d2 = 0) {
     if (hn < n) hn = n;
-    const bool vec = (d % 4 == 0) && (ldh % 4 == 0) && (ldo % 4 == 0) && aligned(H, 16) && aligned(out, 16);
+    const bool vec = (d % 4 == 0) && (d2 % 4 == 0) && (ldh % 4 == 0) && (ldo % 4 == 0) && aligned(H, 16) && aligned(out, 16) &&
+                     (!H2 || aligned(H2, 16));
     if (!vec) {
         hipLaunchKernelGGL((k_spmm_mean_scalar<TRANSPOSED>), dim3((unsigned)n), dim3(128), 0, s, n, rowptr, colidx, H, ldh, d, out, ldo);
         GM_LAUNCH_CHECK();
+        if (H2) {
+            hipLaunchKernelGGL((k_spmm_mean_scalar<TRANSPOSED>), dim3((unsigned)n), dim3(128), 0, s, n, rowptr, colidx, H2, ldh, d2, out + d, ldo);
+            GM_LAUNCH_CHECK();
+        }
         return GM_OK;
     }
+    const int split = (int)(d / 4);
+    if (!H2) { H2 = H; d2 = 0; }
+    d += d2;
     const int nchunks = (int)(d / 4);
     const bool wide = hn > 20480;                         // a 128-byte slab of all rows no longer fits an L2
     const int nslabs = wide ? (nchunks + 127) / 128 : (nchunks + 7) / 8;
@@ -400,8 +412,8 @@ static int launch_spmm(int64_t n, const int32_t* rowptr, const int32_t* colidx, 
     }
     const int64_t blocks = sc.blocks_full * sc.full_rounds + 8 * sc.k_rem;
     GM_REQUIRE(blocks > 0 && blocks < (1ll << 31), "SpMM grid out of range");
-    if (wide) hipLaunchKernelGGL((k_spmm_seg<TRANSPOSED, 64, 2>), dim3((unsigned)blocks), dim3(256), 0, s, n, rowptr, colidx, H, ldh, nchunks, out, ldo, sc);
-    else hipLaunchKernelGGL((k_spmm_seg<TRANSPOSED, 8, 1>), dim3((unsigned)blocks), dim3(256), 0, s, n, rowptr, colidx, H, ldh, nchunks, out, ldo, sc);
+    if (wide) hipLaunchKernelGGL((k_spmm_seg<TRANSPOSED, 64, 2>), dim3((unsigned)blocks), dim3(256), 0, s, n, rowptr, colidx, H, H2, split, ldh, nchunks, out, ldo, sc);
+    else hipLaunchKernelGGL((k_spmm_seg<TRANSPOSED, 8, 1>), dim3((unsigned)blocks), dim3(256), 0, s, n, rowptr, colidx, H, H2, split, ldh, nchunks, out, ldo, sc);
     GM_LAUNCH_CHECK();
     return GM_OK;
 }
@@ -411,6 +423,13 @@ int gm::launch_spmm_mean_rows(int64_t n, int64_t hn, const int32_t* rowptr, cons
                               int64_t d, float* out, int64_t ldo, hipStream_t s) {
     GM_REQUIRE(n > 0 && d > 0 && rowptr && H && out && ldh >= d && ldo >= d, "bad arguments");
     return launch_spmm<false>(n, rowptr, colidx, H, ldh, d, out, ldo, s, hn);
+}
+
+// tower driver, single GPU: A @ [h_X | h_Y] where the two blocks are separate column ranges of hcat (row stride ldh)
+int gm::launch_spmm_mean_two(int64_t n, const int32_t* rowptr, const int32_t* colidx, const float* HX, int64_t dX, const float* HY,
+                             int64_t dY, int64_t ldh, float* out, int64_t ldo, hipStream_t s) {
+    GM_REQUIRE(n > 0 && dX > 0 && dY > 0 && rowptr && HX && HY && out && ldh >= dX && ldh >= dY && ldo >= dX + dY, "bad arguments");
+    return launch_spmm<false>(n, rowptr, colidx, HX, ldh, dX, out, ldo, s, 0, HY, dY);
 }
 
 extern "C" int gm_spmm_mean(int64_t n, const int32_t* rowptr, const int32_t* colidx, const float* H, int64_t ldh, int64_t d,

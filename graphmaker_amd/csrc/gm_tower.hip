@@ -164,8 +164,7 @@ int tower_layer(const TowerCtx& c, int l, const int32_t* rowptr, const int32_t* 
         if (src) {   // gathered buffer: [h_X | h_Y] is one contiguous row, one launch covers both products
             GM_TRY(launch_spmm_mean_rows(rows, c.n, rowptr + r0, colidx, src, ld, c.hX + c.hY, agg, c.ka, c.s));
         } else {
-            GM_TRY(gm_spmm_mean(rows, rowptr + r0, colidx, hXl, ld, c.hX, agg, c.ka, c.stream));
-            GM_TRY(gm_spmm_mean(rows, rowptr + r0, colidx, hYl, ld, c.hY, agg + c.hX, c.ka, c.stream));
+            GM_TRY(launch_spmm_mean_two(rows, rowptr + r0, colidx, hXl, c.hX, hYl, c.hY, ld, agg, c.ka, c.s));   // one launch
         }
     } else {
         // MLPLayer.forward (:387-392): no aggregation, row-local
