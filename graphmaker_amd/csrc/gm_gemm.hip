@@ -132,9 +132,15 @@ k_linear(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t l
         for (int st = 0; st < KT / 4; ++st) {
             float av[TM], bv[TN];
 #pragma unroll
+#ifdef GM_GEMM_X_NOLDS   // exploration only (tools/build_gemm_variant.sh): results are garbage
+            for (int a = 0; a < TM; ++a) av[a] = (float)(lane + a + st);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) bv[b] = (float)(lane - b - st);
+#else
             for (int a = 0; a < TM; ++a) av[a] = as[16 * a * LD + 4 * st];
 #pragma unroll
             for (int b = 0; b < TN; ++b) bv[b] = bs[16 * b * LD + 4 * st];
+#endif
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -148,20 +154,27 @@ k_linear(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t l
     const int64_t T = (K + KT - 1) / KT;                // all tiles (the last one may be ragged)
     // tile `it` lives in LDS buffer it&1; `cur` holds tile it+1 (in flight or landed), `nxt` receives tile it+2
     auto step_fast = [&](int64_t it, Regs& cur, Regs& nxt) {
+#ifndef GM_GEMM_X_NOLOAD
         fetch_fast(nxt, (it + 2) * KT);
+#endif
         __builtin_amdgcn_sched_barrier(0);              // loads above the MFMAs, their first use below them
+#ifndef GM_GEMM_X_NOSTASH
+        // tile it+1 goes to LDS BEFORE this tile's MFMAs (its buffer was last read before the previous barrier): the wave
+        // reaches the barrier straight out of its MFMA run instead of via a load wait and four LDS stores (+2% over the shapes)
+        stash(cur, (int)((it + 1) & 1));
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         multiply((int)(it & 1));
         __builtin_amdgcn_sched_barrier(0);
-        stash(cur, (int)((it + 1) & 1));                // that buffer was last read before the previous barrier
+#ifndef GM_GEMM_X_NOBAR
         __syncthreads();
+#endif
     };
     auto step_any = [&](int64_t it, Regs& cur, Regs& nxt) {
         if (it + 2 < T) fetch_any(nxt, (it + 2) * KT);
+        if (it + 1 < T) stash(cur, (int)((it + 1) & 1));
         multiply((int)(it & 1));
-        if (it + 1 < T) {
-            stash(cur, (int)((it + 1) & 1));
-            __syncthreads();
-        }
+        if (it + 1 < T) __syncthreads();
     };
     fetch_any(r0, 0);
     stash(r0, 0);

@@ -197,10 +197,10 @@ class BaseModel(nn.Module):
         """The second stream of the Sync step (attribute branch beside the edge encoder), one per model and device."""
         st = self.__dict__.get("_side")
         if st is None or st.device != device:
-            # high priority: the attribute branch is the longer of the two (its output layer is 2F wide), so its kernels go
-            # first and the edge encoder fills in around them; both then finish together instead of leaving the attribute
-            # branch to run its tail alone
-            st = self.__dict__["_side"] = torch.cuda.Stream(device=device, priority=-1)
+            # normal priority.  A high-priority stream (the attribute branch is the longer of the two) made both branches end
+            # together and took 0.1 ms off the step, but after a particular sequence of earlier work in the same process a
+            # trajectory then never finished (GPU 100% busy, every kernel here is finite): withdrawn, see DESIGN.md 7b
+            st = self.__dict__["_side"] = torch.cuda.Stream(device=device, priority=0)
         return st
 
     def enable_phase_timing(self, on=True):

@@ -5,4 +5,4 @@ set -e
 cd "$(dirname "$0")/../graphmaker_amd/csrc"
 name=$1; shift
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -I../../include -Wno-unused-function "$@" -c gm_gemm.hip -o /tmp/gm_gemm_$name.o
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../lib/libgm_$name.so gm_tower.o gm_adjacency.o gm_nodeops.o /tmp/gm_gemm_$name.o gm_pair.o gm_attr.o gm_noise.o gm_train.o gm_graphstats.o
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../lib/libgm_$name.so gm_tower.o gm_adjacency.o gm_nodeops.o /tmp/gm_gemm_$name.o gm_onehot.o gm_pair.o gm_pair_bf16.o gm_pair_generic.o gm_attr.o gm_noise.o gm_train.o gm_graphstats.o
