@@ -250,8 +250,8 @@ class BaseModel(nn.Module):
 
     def _draw_t(self, t, T, device):
         """t given (tensor / int) or drawn uniformly from 0..T like model/diffusion.py:582-587; returns (int, tensor)."""
-        if t is None:
-            t = torch.randint(low=0, high=T + 1, size=(1,), device=device)
+        if t is None:     # drawn on the host (torch's CPU generator): the schedule tables are indexed on the host, and a device
+            t = int(torch.randint(low=0, high=T + 1, size=(1,)).item())   # draw would have to be read back (a sync per step)
         t_int = int(t.item()) if torch.is_tensor(t) else int(t)
         if not 0 <= t_int <= T:
             raise ValueError(f"time step {t_int} outside 0..{T}")
