@@ -233,6 +233,7 @@ static inline int gm_build_pair_args(int64_t n, int64_t hE, const float* h, cons
     GM_REQUIRE(wpr >= (n + 31) / 32 && wpr % 4 == 0, "bad wpr");
     GM_REQUIRE(h && W1 && b1 && W2 && b2 && bits_t && tab && out_upper && workspace, "null pointer");
     GM_REQUIRE(aligned(h, 16) && aligned(W1, 16), "h and W1 must be 16-byte aligned");
+    GM_REQUIRE(aligned(bits_t, 8) && aligned(out_upper, 8), "bits_t and out_upper must be 8-byte aligned (two words of a row move at once)");
     GM_REQUIRE(nranges >= 1 && nranges <= MAXR && row_ranges, "between 1 and %d row ranges", MAXR);
     hipStream_t s = as_stream(stream);
     a.n = n; a.h = h; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.bits_t = bits_t; a.wpr = wpr;
