@@ -155,8 +155,8 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
         put_split(W1s + o * LDR, c4, *reinterpret_cast<const float4*>(a.W1 + o * HE + 4 * c4));
     }
     if (tid < HE) { b1s[tid] = a.b1[tid]; b1s2[tid] = a.b1[tid]; }
-    if (tid < HE) dws[tid] = a.W2[HE + tid] - a.W2[tid];
-    if (tid < 2 * HE) W2s[tid] = a.W2[tid];
+    if (tid < HE) dws[tid] = (a.W2[HE + tid] - a.W2[tid]) * RELU_UP;
+    if (tid < 2 * HE) W2s[tid] = a.W2[tid] * RELU_UP;
     const float b20 = a.b2[0], b21 = a.b2[1];
     const float db = b21 - b20;
 

@@ -79,8 +79,8 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_bf16(const PairArgs a)
         }
     }
     if (tid < HE) b1s[tid] = a.b1[tid];
-    if (tid < HE) dws[tid] = a.W2[HE + tid] - a.W2[tid];
-    if (tid < 2 * HE) W2s[tid] = a.W2[tid];
+    if (tid < HE) dws[tid] = (a.W2[HE + tid] - a.W2[tid]) * RELU_UP;
+    if (tid < 2 * HE) W2s[tid] = a.W2[tid] * RELU_UP;
     if (tid < 8) tab_s[tid] = a.tab[((tid & 3) == 0 ? 0 : (tid & 3) == 1 ? 4 : (tid & 3) == 2 ? 2 : 6) + (tid >> 2)];
     const float b20 = a.b2[0], b21 = a.b2[1];
     const float db = b21 - b20;

@@ -99,19 +99,32 @@ __device__ __forceinline__ bool wait_all_ge(lds_flag* flags, int cnt, int need, 
 __device__ __forceinline__ float relu_bits(float x) {   // max(x, 0) for non-NaN x, one integer max
     return __int_as_float(max(__float_as_int(x), 0));
 }
+// ReLU of two hidden units in ONE instruction (there is no packed f32 max; every vector-ALU instruction costs matrix-pipe time):
+// clamp01(x * 2^-63) through the multiply's clamp modifier, against second-layer weights scaled by 2^63 -- oracle relu63: equal
+// to the plain ReLU bit for bit for x <= 0 and 2^-63 <= x <= 2^63 (tools/micro/pk_clamp_relu.hip checks the hardware's clamp).
+constexpr float RELU_DOWN = 0x1p-63f, RELU_UP = 0x1p63f;
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ floatx2 relu63_pk(floatx2 x) {
+    floatx2 r;
+    const floatx2 s = {RELU_DOWN, RELU_DOWN};
+    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(x), "v"(s));
+    return r;
+}
+__device__ __forceinline__ float relu63(float x) {        // the same function on one value (generic kernel)
+    const float c = x * RELU_DOWN;
+    return !(c > 0.0f) ? 0.0f : (c > 1.0f ? 1.0f : c);
+}
 
 // ---- what follows the 128x128 product of a row-unit in both matrix-core kernels (f32: gm_pair.hip, bf16: gm_pair_bf16.hip):
 // second layer, softmax, posterior, draw, bitmap word.  acc[strip][o-tile] is the 32x32 MFMA accumulator layout: lane
 // (l31 = column = pair, half) holds hidden units o = 32 mt + 8 g + 4 half + r in register 4 g + r of tile mt.
 struct EpiCtx {
-    const float* dws;       // LDS: W2[1] - W2[0]
-    const float* W2s;       // LDS: both rows of W2 (DBG only)
+    const float* dws;       // LDS: (W2[1] - W2[0]) * 2^63 (RELU_UP)
+    const float* W2s;       // LDS: both rows of W2, * 2^63 (DBG only)
     const float* tab_s;     // LDS: posterior table as two rows [E_t bit][4] = tab[e], tab[4+e], tab[2+e], tab[6+e]
     uint32_t* rng_mine;     // LDS: this wave's 256 Philox words, [4 row-units][64 columns]
     float db, b20, b21;     // b2[1] - b2[0], b2[0], b2[1]
 };
-typedef float floatx2 __attribute__((ext_vector_type(2)));
-
 template <bool DBG>
 __device__ __forceinline__ void pair_epilogue(const PairArgs& a, const EpiCtx& c, floatx16 (&acc)[2][4], int64_t i, int64_t i0,
                                               int64_t j0, int tj, int unit, int ub, int wv, int lane) {
@@ -133,8 +146,8 @@ __device__ __forceinline__ void pair_epilogue(const PairArgs& a, const EpiCtx& c
                 const int ob = mt * 32 + 8 * g + 4 * half;
                 const float4 wd = *reinterpret_cast<const float4*>(c.dws + ob);
                 const floatx2 wlo = {wd.x, wd.y}, whi = {wd.z, wd.w};
-                const floatx2 xlo = {relu_bits(acc[s][mt][4 * g + 0]), relu_bits(acc[s][mt][4 * g + 1])};
-                const floatx2 xhi = {relu_bits(acc[s][mt][4 * g + 2]), relu_bits(acc[s][mt][4 * g + 3])};
+                const floatx2 xlo = relu63_pk(floatx2{acc[s][mt][4 * g + 0], acc[s][mt][4 * g + 1]});
+                const floatx2 xhi = relu63_pk(floatx2{acc[s][mt][4 * g + 2], acc[s][mt][4 * g + 3]});
                 asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(dd) : "v"(xlo), "v"(wlo));
                 asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(dd) : "v"(xhi), "v"(whi));
                 if (DBG) {

@@ -73,8 +73,8 @@ k_pair_generic(const GenArgs a) {
         const float* w = a.W1 + (int64_t)o * hE;        // wave-uniform row
         float acc = a.b1[o];
         for (int k = 0; k < hE; ++k) acc = __builtin_fmaf(z[k * 64 + lane], w[k], acc);
-        const float hid = acc > 0.0f ? acc : 0.0f;
-        const float dw = a.W2[hE + o] - a.W2[o];
+        const float hid = relu63(acc);                            // oracle relu63: against weights scaled by 2^63
+        const float dw = (a.W2[hE + o] - a.W2[o]) * RELU_UP;
         const int hs = (o >> 2) & 1, par = o & 1;                 // wave-uniform
 #pragma unroll
         for (int x = 0; x < 2; ++x)
@@ -83,8 +83,8 @@ k_pair_generic(const GenArgs a) {
                 if (hs == x && par == y) {
                     sd[x][y] = __builtin_fmaf(hid, dw, sd[x][y]);
                     if (dbg) {
-                        t0[x][y] = __builtin_fmaf(hid, a.W2[o], t0[x][y]);
-                        t1[x][y] = __builtin_fmaf(hid, a.W2[hE + o], t1[x][y]);
+                        t0[x][y] = __builtin_fmaf(hid, a.W2[o] * RELU_UP, t0[x][y]);
+                        t1[x][y] = __builtin_fmaf(hid, a.W2[hE + o] * RELU_UP, t1[x][y]);
                     }
                 }
     }

@@ -165,7 +165,9 @@ int gm_hadamard_gather(int64_t B, int64_t d, const int64_t* src, const int64_t* 
  * (rows [row_begin,row_end), words w >= (row>>5) are written).
  * hE = 128 (every shipped configuration) runs the f32 matrix-core kernel (gm_pair.hip); any other 1 <= hE <= 512, which the
  * reference also accepts (model/gnn.py:204-231), runs a vector-ALU kernel with the same arithmetic orders and the same
- * bits as the oracle (gm_pair_generic.hip; it does not use `workspace`).  h and W1 16-byte aligned, bits_t and out_upper
+ * bits as the oracle (gm_pair_generic.hip; it does not use `workspace`).  The hidden ReLU is exact for activations that are
+ * <= 0 or within [2^-63, 2^63] (it is evaluated as clamp01(x * 2^-63) against second-layer weights scaled by 2^63, which must
+ * therefore stay below 2^64 in magnitude); smaller positive activations are rounded to multiples of 2^-86, larger ones saturate.  h and W1 16-byte aligned, bits_t and out_upper
  * 8-byte aligned with wpr a multiple of 4 (rows then stay aligned).  tab: HOST pointer to 8 floats tab[(i*2+k)*2+e] = Q_t[k][e]*Qbar_s[i][k]/Qbar_t[i][e].
  * workspace: >= 256 bytes, zeroed by the caller when it is allocated.  Word 0 is the tile counter (cleared by every
  * call).  Word 16 is a sticky trouble flag: the kernel's waves hand tiles to each other through flags in LDS without

@@ -582,6 +582,16 @@ void gmo_onehot_linear(int64_t n, int64_t F, int64_t H, const float* X_one_hot, 
  *         logit[c]  = (S0 + S1) + b2[c],  S_h = C[h][0] + C[h][1],  C[h][p] = fmaf chain over ascending o with
  *         ((o>>2)&1)==h and (o&1)==p  (h: the split a 32x32 MFMA accumulator tile gives the two half-waves; p: even / odd
  *         hidden units sit in adjacent accumulator registers, so one packed FMA advances both chains). */
+/* ReLU of the pair MLP's hidden layer, in the form the GPU evaluates it: one packed multiply with the hardware clamp to
+ * [0,1] -- relu(x) * w == clamp01(x * 2^-63) * (w * 2^63).  Both scalings are exact, so this equals the plain ReLU bit for
+ * bit for x <= 0 and for 2^-63 <= x <= 2^63; a smaller positive x (|x| < 1.1e-19) comes back rounded to a multiple of
+ * 2^-86 (its product with a weight is far below the resolution of any logit it is added to), a larger x saturates at
+ * 2^63 (9.2e18: no model has such activations), NaN gives 0. */
+static inline float relu63(float x) {
+    float c = x * 0x1p-63f;
+    return !(c > 0.0f) ? 0.0f : (c > 1.0f ? 1.0f : c);
+}
+
 void gmo_pair_logits(int64_t hE, const float* hi, const float* hj, const float* W1, const float* b1,
                      const float* W2, const float* b2, float logit[2]) {
     float z[1024], hid[1024];
@@ -590,13 +600,13 @@ void gmo_pair_logits(int64_t hE, const float* hi, const float* hj, const float* 
         float acc = b1[o];
         const float* w = W1 + o * hE;
         for (int64_t k = 0; k < hE; ++k) acc = fmaf(z[k], w[k], acc);
-        hid[o] = acc > 0.0f ? acc : 0.0f;
+        hid[o] = relu63(acc);
     }
     for (int c = 0; c < 2; ++c) {
         float s[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
         for (int64_t o = 0; o < hE; ++o) {
             int hsel = (int)((o >> 2) & 1), par = (int)(o & 1);
-            s[hsel][par] = fmaf(hid[o], W2[c * hE + o], s[hsel][par]);
+            s[hsel][par] = fmaf(hid[o], W2[c * hE + o] * 0x1p63f, s[hsel][par]);
         }
         logit[c] = ((s[0][0] + s[0][1]) + (s[1][0] + s[1][1])) + b2[c];
     }
@@ -612,7 +622,7 @@ void gmo_pair_score_sample(int64_t n, int64_t hE, const float* h, const float* W
     for (int64_t o = 0; o < hE; ++o)
         for (int64_t k = 0; k < hE; ++k) W1t[k * hE + o] = W1[o * hE + k];
     float dw[1024];
-    for (int64_t o = 0; o < hE; ++o) dw[o] = W2[hE + o] - W2[o];
+    for (int64_t o = 0; o < hE; ++o) dw[o] = (W2[hE + o] - W2[o]) * 0x1p63f;     /* scaled: see relu63 */
     const float db = b2[1] - b2[0];
 #pragma omp parallel for schedule(dynamic, 1)
     for (int64_t i = row_begin; i < row_end; ++i) {
@@ -659,7 +669,7 @@ void gmo_pair_score_sample(int64_t n, int64_t hE, const float* h, const float* W
                  * C[h][p] = fmaf chain over ascending o with ((o>>2)&1)==h, (o&1)==p (see gmo_pair_logits) */
                 float s[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
                 for (int64_t o = 0; o < hE; ++o) {
-                    float r = hid[b][o] > 0.0f ? hid[b][o] : 0.0f;
+                    float r = relu63(hid[b][o]);
                     int hsel = (int)((o >> 2) & 1), par = (int)(o & 1);
                     s[hsel][par] = fmaf(r, dw[o], s[hsel][par]);
                 }
@@ -675,9 +685,9 @@ void gmo_pair_score_sample(int64_t n, int64_t hE, const float* h, const float* W
                     for (int c = 0; c < 2; ++c) {
                         float t[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
                         for (int64_t o = 0; o < hE; ++o) {
-                            float rl = hid[b][o] > 0.0f ? hid[b][o] : 0.0f;
+                            float rl = relu63(hid[b][o]);
                             int hsel = (int)((o >> 2) & 1), par = (int)(o & 1);
-                            t[hsel][par] = fmaf(rl, W2[c * hE + o], t[hsel][par]);
+                            t[hsel][par] = fmaf(rl, W2[c * hE + o] * 0x1p63f, t[hsel][par]);
                         }
                         logits_dbg[2 * r + c] = ((t[0][0] + t[0][1]) + (t[1][0] + t[1][1])) + b2[c];
                     }
