@@ -18,14 +18,19 @@
 //
 // Tiling: persistent workgroups (512 threads = 8 waves, 2 per SIMD) pull 64x64 tiles of the upper triangle from an
 // atomic counter.  The two waves of a SIMD (w and w+4) take turns on the matrix pipe: one runs the 512 MFMAs of its
-// next row (both 32-column strips) while the other runs the VALU epilogue of the row it has just finished; the turn
-// passes through a flag in LDS.  (Left to the hardware, the older wave wins every MFMA arbitration, the younger one
-// starves and later runs alone with its epilogues exposed.)  LDS fragments for k-block q+1 are read while the MFMAs
-// of block q run.  The alternation runs straight through tile changes: there is no workgroup barrier in the loop.
+// next row (both 32-column strips) while the other runs the epilogue of the row it has just finished and fetches what
+// its next row needs (b1 into the accumulators, the first fragment); the turn passes through a flag in LDS.  (Left to
+// the hardware, the older wave wins every MFMA arbitration, the younger one starves and later runs alone.)  LDS
+// fragments for k-block q+1 are read while the MFMAs of block q run; the k loop is fully unrolled, so every LDS offset
+// is an immediate.  The alternation runs straight through tile changes: there is no workgroup barrier in the loop.
 // Waves 0-3 finish a tile one row-unit before waves 4-7; in that time they fetch the next queue item and load its h
 // rows into the (now dead) accumulator registers, and write them to LDS as soon as every wave has issued its last
-// fragment read of the old tile -- while waves 4-7 are still in their last epilogue, which reads no h rows.  Measured anatomy of one 512-MFMA row-unit (ideal 32,768 cycles): 33.9k with operands in
-// registers, +1.9k for the 176 ds_read_b128 that feed it, +~1k hand-over/epilogue interference (profiles/).
+// fragment read of the old tile -- while waves 4-7 are still in their last epilogue, which reads no h rows.
+// What bounds the kernel (tools/micro/): on gfx950 a vector-ALU instruction of ANY wave of a SIMD costs
+// that SIMD 4-7 cycles of matrix-pipe time (the two do not overlap), LDS reads cost none.  A row-unit is therefore
+// 512 x 65 cycles of MFMA plus ~5 cycles for every VALU instruction issued for it, and the code keeps those few:
+// packed z products, packed ReLU (clamp modifier) and packed second-layer FMAs, one Philox block per four row-units,
+// tile decoding and addresses on the scalar unit (pair_epilogue in gm_pair_common.h).
 // W1 (64 KB) stays in LDS for the whole kernel; per tile the 64 h_i rows and 64 h_j rows are staged (64 KB), i.e.
 // 16 B of HBM/L2 traffic per pair against 33,408 FLOP: MFMA-bound (f32 matrix peak 157 TFLOP/s).
 #include "gm_pair_common.h"
