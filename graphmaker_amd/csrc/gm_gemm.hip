@@ -249,9 +249,25 @@ extern "C" int gm_linear(int64_t M, int64_t N, int64_t K, const float* A, int64_
     return launch_linear<GM_GEMM_CFG>(M, N, K, A, lda, W, ldw, bias, C, ldc, relu, s);
 #endif
     const int64_t tiles128 = ((N + 127) / 128) * ((M + 127) / 128);
-    // wide layers with many rows: 128x128 block tile, 4x2 waves of 32x64 (half the operand traffic per FLOP);
+    // wide layers with many rows: 128x256 block tile, 4x4 waves of 32x64 (a third of the operand traffic per FLOP of the 64x64 tile);
     // everything else: 64x64 block tile, 2x2 waves of 32x32, four workgroups per CU
-    if (tiles128 >= GM_GEMM_BIG_TILES) return launch_linear<2, 4, 32, 2, 4, 2>(M, N, K, A, lda, W, ldw, bias, C, ldc, relu, s);
+    // (16 waves, 4x4 of 32x64, one workgroup per CU: 13752x1744x1744 113 -> 124 TFLOP/s, the 512-wide layers +5% over the
+    // 8-wave 128x128 tile with two workgroups per CU that was here before; 256x128 measures the same)
+    if (tiles128 >= GM_GEMM_BIG_TILES) {
+        // ... unless its grid quantises clearly worse on this chip than the 8-wave 128x128 tile's (two workgroups per CU):
+        // 2708 x 2866 (Cora's attribute head) is 264 tiles of 128x256 -- one full round and 8 stragglers -- but 506 of 128x128
+        static int cus = 0;
+        if (cus == 0) {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+            else cus = 256;
+        }
+        const int64_t tiles256 = ((N + 255) / 256) * ((M + 127) / 128);
+        const double fill16 = (double)tiles256 / (double)(((tiles256 + cus - 1) / cus) * cus);
+        const double fill8 = (double)tiles128 / (double)(((tiles128 + 2 * cus - 1) / (2 * cus)) * 2 * cus);
+        if (fill16 >= fill8 - 0.05) return launch_linear<2, 4, 32, 1, 4, 4>(M, N, K, A, lda, W, ldw, bias, C, ldc, relu, s);
+        return launch_linear<2, 4, 32, 2, 4, 2>(M, N, K, A, lda, W, ldw, bias, C, ldc, relu, s);
+    }
     // few 64x64 tiles (a rank's row block, Cora-sized graphs, the 128- and 64-wide layers): the serial K walk of one
     // workgroup is the whole run time, so halve the rows per wave and double the workgroups (32x64 block tile)
     const int64_t tiles64 = ((N + 63) / 64) * ((M + 63) / 64);
