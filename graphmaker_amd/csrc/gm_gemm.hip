@@ -254,18 +254,21 @@ extern "C" int gm_linear(int64_t M, int64_t N, int64_t K, const float* A, int64_
     // (16 waves, 4x4 of 32x64, one workgroup per CU: 13752x1744x1744 113 -> 124 TFLOP/s, the 512-wide layers +5% over the
     // 8-wave 128x128 tile with two workgroups per CU that was here before; 256x128 measures the same)
     if (tiles128 >= GM_GEMM_BIG_TILES) {
-        // ... unless its grid quantises clearly worse on this chip than the 8-wave 128x128 tile's (two workgroups per CU):
-        // 2708 x 2866 (Cora's attribute head) is 264 tiles of 128x256 -- one full round and 8 stragglers -- but 506 of 128x128
+        // ... unless it wastes clearly more of the chip than the 8-wave 128x128 tile (two workgroups per CU) would:
+        // 2708 x 2866 (Cora's attribute head) is 264 tiles of 128x256 -- one full round and 8 stragglers -- but 506 of 128x128;
+        // the training batch's 2097152 x 128 pair layer would compute 128 columns of padding per tile
         static int cus = 0;
         if (cus == 0) {
             int dev = 0, v = 0;
             if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
             else cus = 256;
         }
+        // useful outputs / outputs computed over whole rounds of the grid (tile padding and the partly empty last round)
         const int64_t tiles256 = ((N + 255) / 256) * ((M + 127) / 128);
-        const double fill16 = (double)tiles256 / (double)(((tiles256 + cus - 1) / cus) * cus);
-        const double fill8 = (double)tiles128 / (double)(((tiles128 + 2 * cus - 1) / (2 * cus)) * 2 * cus);
-        if (fill16 >= fill8 - 0.05) return launch_linear<2, 4, 32, 1, 4, 4>(M, N, K, A, lda, W, ldw, bias, C, ldc, relu, s);
+        const double useful = (double)M * (double)N;
+        const double eff16 = useful / ((double)(((tiles256 + cus - 1) / cus) * cus) * 128.0 * 256.0);
+        const double eff8 = useful / ((double)(((tiles128 + 2 * cus - 1) / (2 * cus)) * 2 * cus) * 128.0 * 128.0);
+        if (eff16 >= 0.95 * eff8) return launch_linear<2, 4, 32, 1, 4, 4>(M, N, K, A, lda, W, ldw, bias, C, ldc, relu, s);
         return launch_linear<2, 4, 32, 2, 4, 2>(M, N, K, A, lda, W, ldw, bias, C, ldc, relu, s);
     }
     // few 64x64 tiles (a rank's row block, Cora-sized graphs, the 128- and 64-wide layers): the serial K walk of one
