@@ -254,13 +254,9 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
 #ifdef GM_PAIR_STAMP
                 const unsigned long long m1 = STAMP();
 #endif
-#ifndef GM_PAIR_PRIO
-#define GM_PAIR_PRIO 1
-#endif
-                if (GM_PAIR_PRIO == 1) __builtin_amdgcn_s_setprio(1);
-                if (GM_PAIR_PRIO == 2) __builtin_amdgcn_s_setprio(0);
-                if (GM_PAIR_PRIO == 3 && grp == 0) __builtin_amdgcn_s_setprio(1);
-                if (GM_PAIR_PRIO == 4) __builtin_amdgcn_s_setprio(1);
+                // the multiplying wave outranks its partner at the SIMD's issue arbiter (no priorities: 22.8 instead of 21.9 ms;
+                // epilogue wave high, or one group only: no difference -- DESIGN.md 4.1)
+                __builtin_amdgcn_s_setprio(1);
                 // fragments for k-block q+1 are read from LDS while the 32 MFMAs of block q run; fully unrolled: every
                 // LDS offset is an immediate, no address arithmetic between the MFMAs
 #pragma unroll
@@ -278,10 +274,7 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
                     if (q + 2 < HE / 8) prep_frag(f0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (GM_PAIR_PRIO == 1) __builtin_amdgcn_s_setprio(0);
-                if (GM_PAIR_PRIO == 2) __builtin_amdgcn_s_setprio(2);
-                if (GM_PAIR_PRIO == 3 && grp == 0) __builtin_amdgcn_s_setprio(0);
-                if (GM_PAIR_PRIO == 4) { if (grp == 0) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
+                __builtin_amdgcn_s_setprio(0);
 #ifdef GM_PAIR_STAMP
                 asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[1][3]));
                 st_mma += STAMP() - m1;
