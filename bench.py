@@ -101,8 +101,8 @@ def cpu_baseline(wl, model, state, budget_rows=768, threads=None):
     orc.pair_score_sample(n, h, pair, bits_np, tab_E, seed=0, step=T, row_begin=0, row_end=rows)
     t_pair = time.perf_counter() - t0
     t0 = time.perf_counter()
-    logits = towerX.forward(np.float32(1.0), oh_np, y_np, rp, ci)
-    orc.attr_posterior_sample(logits, x_np, tab_X, seed=0, step=T)
+    diff = towerX.forward(np.float32(1.0), oh_np, y_np, rp, ci, diff_head=True)     # the sampler's half-width head, as timed
+    orc.attr_posterior_sample(diff, x_np, tab_X, seed=0, step=T, diff=True)
     t_tower_x = time.perf_counter() - t0
     P = n * (n - 1) // 2
     p_sample = sum(n - 1 - i for i in range(rows))

@@ -16,7 +16,7 @@ EXPORTS = [
     "gm_version", "gm_last_error", "gm_device_cus",
     "gm_bitmap_from_dense_i64", "gm_dense_i64_from_bitmap", "gm_symmetrize_upper", "gm_csr_rowptr", "gm_csr_rowptr_capped", "gm_csr_fill",
     "gm_bitmap_from_upper_edges", "gm_upper_edges_ranges", "gm_bitmap_from_edge_segments", "gm_spmm_mean", "gm_linear", "gm_layernorm", "gm_tower_workspace_bytes",
-    "gm_tower_forward", "gm_tower_stage", "gm_tower_prep_floats", "gm_tower_prepare", "gm_onehot_prep_floats", "gm_onehot_prepare", "gm_onehot_linear", "gm_hadamard_gather", "gm_pair_score_sample", "gm_pair_score_sample_ranges", "gm_pair_score_sample_bf16", "gm_attr_posterior_sample", "gm_onehot_from_x",
+    "gm_tower_forward", "gm_tower_stage", "gm_tower_prep_floats", "gm_tower_prepare", "gm_onehot_prep_floats", "gm_onehot_prepare", "gm_onehot_linear", "gm_hadamard_gather", "gm_pair_score_sample", "gm_pair_score_sample_ranges", "gm_pair_score_sample_bf16", "gm_attr_posterior_sample", "gm_attr_posterior_sample_diff", "gm_head_diff_prepare", "gm_onehot_from_x",
     "gm_x_from_onehot", "gm_prior_Y", "gm_prior_X", "gm_prior_E", "gm_prior_E_static",
     "gm_noise_E", "gm_noise_X", "gm_bitmap_from_onehot_f32", "gm_x_from_onehot3d",
     "gm_gemm_workspace_bytes", "gm_gemm", "gm_colsum_workspace_bytes", "gm_colsum", "gm_layernorm_fwd",

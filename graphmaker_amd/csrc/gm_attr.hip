@@ -2,6 +2,8 @@
 //   gm_attr_posterior_sample : softmax over the class dim (model/diffusion.py:879), per-attribute posterior
 //                              (:884-894 via BaseModel.posterior :351-406) and sample_X (:214-237) in one pass,
 //                              writing the uint8 state and (optionally) the (n,2F) float one-hot the towers read.
+//   gm_attr_posterior_sample_diff / gm_head_diff_prepare : the same draw from the logit DIFFERENCE l1 - l0 that a
+//                              node tower with the half-width head W[2f+1] - W[2f] puts out (half the output GEMM).
 //   gm_prior_Y / gm_prior_X / gm_prior_E : model/diffusion.py:831-844 (sample_E :188-212 keeps diagonal draws).
 #include <mutex>
 
@@ -9,6 +11,8 @@
 
 namespace gm {
 
+// DIFF: `logits` is (n,F), the difference l1 - l0 per attribute (softmax([l0,l1]) = softmax([0,d]), as in the pair kernel)
+template <bool DIFF>
 __global__ void k_attr_posterior_sample(int64_t n, int64_t F, const float* __restrict__ logits,
                                         const uint8_t* __restrict__ x_t, const float* __restrict__ tab,
                                         const float* __restrict__ u, uint64_t seed, uint32_t step, int64_t v_begin,
@@ -18,9 +22,13 @@ __global__ void k_attr_posterior_sample(int64_t n, int64_t F, const float* __res
     const int64_t v = v_begin + blockIdx.x, f = (int64_t)blockIdx.y * blockDim.x + threadIdx.x;
     if (f >= F) return;
     const int64_t g = v * F + f;
-    const float2 l = *reinterpret_cast<const float2*>(logits + 2 * g);
     float q0, q1, p0, p1;
-    softmax2(l.x, l.y, q0, q1);
+    if (DIFF) {
+        softmax2_diff(logits[g], q0, q1);
+    } else {
+        const float2 l = *reinterpret_cast<const float2*>(logits + 2 * g);
+        softmax2(l.x, l.y, q0, q1);
+    }
     posterior2(tab + 8 * f, (int)x_t[g], q0, q1, p0, p1);
     const int64_t idx = f * n + v;   // reshape(-1, 2) of the (F, n, 2) tensor, model/diffusion.py:228-230
     const float uu = u ? u[idx] : u_idx64(seed, step, STREAM_X, (uint64_t)idx);
@@ -28,6 +36,17 @@ __global__ void k_attr_posterior_sample(int64_t n, int64_t F, const float* __res
     x_s[g] = b ? 1 : 0;
     if (onehot) *reinterpret_cast<float2*>(onehot + 2 * g) = b ? make_float2(0.f, 1.f) : make_float2(1.f, 0.f);
     if (post) *reinterpret_cast<float2*>(post + 2 * g) = make_float2(p0, p1);
+}
+
+// Wd[f][k] = W[2f+1][k] - W[2f][k], bd[f] = b[2f+1] - b[2f]: the last Linear of a node tower folded to one output per
+// attribute (one thread per element of Wd; the first F threads also write bd)
+__global__ void k_head_diff(int64_t F, int64_t Hc, const float* __restrict__ W, const float* __restrict__ b,
+                            float* __restrict__ Wd, float* __restrict__ bd) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= F * Hc) return;
+    const int64_t f = g / Hc, k = g - f * Hc;
+    Wd[g] = W[(2 * f + 1) * Hc + k] - W[2 * f * Hc + k];
+    if (g < F) bd[g] = b[2 * g + 1] - b[2 * g];
 }
 
 __global__ void k_onehot_from_x(int64_t total, const uint8_t* __restrict__ x, float* __restrict__ onehot) {
@@ -97,18 +116,40 @@ using namespace gm;
 
 static inline unsigned blocks_for(int64_t total) { return (unsigned)((total + 255) / 256); }
 
-extern "C" int gm_attr_posterior_sample(int64_t n, int64_t F, const float* logits, const uint8_t* x_t, const float* tab,
-                                        const float* u, uint64_t seed, uint32_t step, int64_t v_begin, int64_t v_end,
-                                        uint8_t* x_s, float* onehot_out, float* post_dbg, gm_stream_t stream) {
+template <bool DIFF>
+static int attr_posterior_sample(int64_t n, int64_t F, const float* logits, const uint8_t* x_t, const float* tab,
+                                 const float* u, uint64_t seed, uint32_t step, int64_t v_begin, int64_t v_end,
+                                 uint8_t* x_s, float* onehot_out, float* post_dbg, gm_stream_t stream) {
     GM_REQUIRE(n > 0 && F > 0 && logits && x_t && tab && x_s, "bad arguments");
     GM_REQUIRE(0 <= v_begin && v_begin <= v_end && v_end <= n, "bad node range [%lld,%lld)", (long long)v_begin, (long long)v_end);
     if (v_begin == v_end) return GM_OK;
     GM_REQUIRE(n * F < (1ll << 39), "n*F too large");
-    GM_REQUIRE(aligned(logits, 8) && (!onehot_out || aligned(onehot_out, 8)) && (!post_dbg || aligned(post_dbg, 8)),
-               "logits/onehot/post must be 8-byte aligned");
+    GM_REQUIRE(aligned(logits, DIFF ? 4 : 8) && (!onehot_out || aligned(onehot_out, 8)) && (!post_dbg || aligned(post_dbg, 8)),
+               "logits/onehot/post must be 8-byte aligned (a logit difference: 4-byte)");
     GM_REQUIRE(v_end - v_begin < (1ll << 31) && (F + 255) / 256 <= 65535, "grid too large");
-    hipLaunchKernelGGL(k_attr_posterior_sample, dim3((unsigned)(v_end - v_begin), (unsigned)((F + 255) / 256)), dim3(256), 0, as_stream(stream), n, F,
-                       logits, x_t, tab, u, seed, step, v_begin, v_end, x_s, onehot_out, post_dbg);
+    hipLaunchKernelGGL(k_attr_posterior_sample<DIFF>, dim3((unsigned)(v_end - v_begin), (unsigned)((F + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), n, F, logits, x_t, tab, u, seed, step, v_begin, v_end, x_s, onehot_out, post_dbg);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
+
+extern "C" int gm_attr_posterior_sample(int64_t n, int64_t F, const float* logits, const uint8_t* x_t, const float* tab,
+                                        const float* u, uint64_t seed, uint32_t step, int64_t v_begin, int64_t v_end,
+                                        uint8_t* x_s, float* onehot_out, float* post_dbg, gm_stream_t stream) {
+    return attr_posterior_sample<false>(n, F, logits, x_t, tab, u, seed, step, v_begin, v_end, x_s, onehot_out, post_dbg, stream);
+}
+
+extern "C" int gm_attr_posterior_sample_diff(int64_t n, int64_t F, const float* diff, const uint8_t* x_t, const float* tab,
+                                             const float* u, uint64_t seed, uint32_t step, int64_t v_begin, int64_t v_end,
+                                             uint8_t* x_s, float* onehot_out, float* post_dbg, gm_stream_t stream) {
+    return attr_posterior_sample<true>(n, F, diff, x_t, tab, u, seed, step, v_begin, v_end, x_s, onehot_out, post_dbg, stream);
+}
+
+extern "C" int gm_head_diff_prepare(int64_t F, int64_t Hc, const float* W, const float* b, float* Wd, float* bd,
+                                    gm_stream_t stream) {
+    GM_REQUIRE(F > 0 && Hc > 0 && W && b && Wd && bd, "bad arguments");
+    GM_REQUIRE(F * Hc < (1ll << 39), "F*Hc too large");
+    hipLaunchKernelGGL(k_head_diff, dim3(blocks_for(F * Hc)), dim3(256), 0, as_stream(stream), F, Hc, W, b, Wd, bd);
     GM_LAUNCH_CHECK();
     return GM_OK;
 }

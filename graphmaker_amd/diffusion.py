@@ -337,19 +337,22 @@ class BaseModel(nn.Module):
         return A_t, bits_s
 
     def _logits_fn(self, pred_X, t_float, x_onehot, Y32, A_t, plan, group, x_u8=None):
-        """rows -> (n, 2F) attribute logits valid on `rows` (all rows on a single GPU)."""
+        """rows -> (n, F) attribute logit differences l1 - l0 valid on `rows` (all rows on a single GPU).  The sampler only
+        takes softmax(logits) (model/diffusion.py:879), a function of the difference, so the node tower runs with its
+        half-width head (gnn._TowerBase._head): half of its largest GEMM."""
         if plan is None:
-            return lambda rows: pred_X._run(t_float, x_onehot, Y32, A_t, x_u8=x_u8)
+            return lambda rows: pred_X._run(t_float, x_onehot, Y32, A_t, x_u8=x_u8, diff_head=True)
         n = self.num_nodes
 
         def sharded(rows):
-            out = self._buf("logits", (n, pred_X._dims.out_size), torch.float32, x_onehot.device)
-            return pred_X._run_sharded(t_float, x_onehot, Y32, A_t, plan, group, out, parallel.all_gather_node_rows, x_u8=x_u8)
+            out = self._buf("logit_diff", (n, self.num_attrs_X), torch.float32, x_onehot.device)
+            return pred_X._run_sharded(t_float, x_onehot, Y32, A_t, plan, group, out, parallel.all_gather_node_rows, x_u8=x_u8,
+                                       diff_head=True)
         return sharded
 
     def _attribute_draw(self, logits_fn, x, tab_X, seed, step, u=None, plan=None, group=None):
         """softmax + posterior + sample_X (model/diffusion.py:879-895) on this rank's node rows, then replicate.
-        logits_fn(rows) -> (n, 2F) logits valid on `rows`."""
+        logits_fn(rows) -> (n, F) logit differences valid on `rows` (_logits_fn)."""
         n = self.num_nodes
         dev = x.device
         rows = None if plan is None else plan.node_range()
@@ -358,11 +361,11 @@ class BaseModel(nn.Module):
         tabX_dev = self._const(("tab_X", step, tab_X.tobytes()), tab_X, dev)
         if plan is None:
             with self.phase("attr"):
-                return ops.attr_posterior_sample(logits, x, tabX_dev, seed=seed, step=step, u=u)
+                return ops.attr_posterior_sample(logits, x, tabX_dev, seed=seed, step=step, u=u, diff=True)
         x_pad = self._buf("x_pad", (plan.world * plan.node_rows, x.shape[1]), torch.uint8, dev)
         with self.phase("attr"):
             ops.attr_posterior_sample(logits, x, tabX_dev, seed=seed, step=step, u=u, rows=rows, x_s=x_pad[:n],
-                                      want_onehot=False)
+                                      want_onehot=False, diff=True)
         with self.phase("allgather_X"):
             x_s = parallel.all_gather_node_rows(plan, x_pad, group)[:n].clone()      # x_pad is reused by the next step
         with self.phase("attr"):
@@ -509,12 +512,12 @@ class ModelSync(BaseModel):
         with self.phase("csr"):      # only the rows this rank aggregates (its node block)
             A_t = ops.adjacency_from_bitmap(bits_t, n, workspace=self._csr_ws(dev), rows=plan.node_range())
         h_pad = self._buf("h_pad", (plan.world * plan.node_rows, enc._dims.out_size), torch.float32, dev)
-        logits = self._buf("logits", (n, pred_X._dims.out_size), torch.float32, dev)
+        logits = self._buf("logit_diff", (n, self.num_attrs_X), torch.float32, dev)      # l1 - l0 per attribute (_logits_fn)
         x_pad = self._buf("x_pad", (plan.world * plan.node_rows, x.shape[1]), torch.uint8, dev)
         start = parallel.start_all_gather_node_rows
         with self.phase("towers"):
             stages = [enc._sharded_stages(t_float, x_onehot, Y32, A_t, plan, group, h_pad[:n], start, x_u8=x),
-                      pred_X._sharded_stages(t_float, x_onehot, Y32, A_t, plan, group, logits, start, x_u8=x)]
+                      pred_X._sharded_stages(t_float, x_onehot, Y32, A_t, plan, group, logits, start, x_u8=x, diff_head=True)]
             while stages:
                 for g in list(stages):
                     try:
@@ -524,7 +527,7 @@ class ModelSync(BaseModel):
         h_on_wire = start(plan, h_pad, group)                        # node embeddings of every rank (pair kernel input)
         with self.phase("attr"):                                     # ... while this rank draws its attribute rows
             ops.attr_posterior_sample(logits, x, self._const(("tab_X", t, tab_X.tobytes()), tab_X, dev), seed=seed, step=t, u=uX,
-                                      rows=plan.node_range(), x_s=x_pad[:n], want_onehot=False)
+                                      rows=plan.node_range(), x_s=x_pad[:n], want_onehot=False, diff=True)
         x_on_wire = start(plan, x_pad, group)                        # travels under the pair kernel
         with self.phase("allgather_h"):
             h_on_wire.wait()

@@ -95,6 +95,31 @@ class _TowerBase(nn.Module):
             self._ptr_key = key
         return self._ptr_arr
 
+    def _head(self, diff):
+        """(dims, parameter pointers) of the fused calls.  diff: the sampler's half-width head -- mlp_out.2 folded to the
+        logit difference l1 - l0 per attribute (gm_head_diff_prepare; out_size F instead of 2F), recomputed when mlp_out.2
+        has been updated.  forward() and training keep the two-logit head."""
+        ptrs = self._param_ptrs()
+        if not diff:
+            return self._dims, ptrs
+        if self.num_classes_X != 2 or self._dims.out_size != 2 * self.num_attrs_X:
+            raise ValueError("the logit-difference head needs a two-class attribute head (out_size = 2 * num_attrs_X)")
+        w, b = self.mlp_out[2].weight, self.mlp_out[2].bias
+        key = (w.data_ptr(), w._version, b.data_ptr(), b._version)
+        if key != getattr(self, "_diff_key", None):
+            self._diff_wb = ops.head_diff(w.detach(), b.detach())
+            d = self._dims
+            self._diff_dims = TowerDims(in_X=d.in_X, num_classes_Y=d.num_classes_Y, hidden_t=d.hidden_t, hidden_X=d.hidden_X,
+                                        hidden_Y=d.hidden_Y, num_layers=d.num_layers, out_size=d.out_size // 2,
+                                        is_mlp=d.is_mlp)
+            self._diff_key = key
+        if getattr(self, "_diff_ptr_key", None) != (self._ptr_key, self._diff_key):
+            arr = (C.c_void_p * len(ptrs))(*ptrs)
+            arr[len(ptrs) - 2], arr[len(ptrs) - 1] = self._diff_wb[0].data_ptr(), self._diff_wb[1].data_ptr()
+            self._diff_ptrs = arr
+            self._diff_ptr_key = (self._ptr_key, self._diff_key)
+        return self._diff_dims, self._diff_ptrs
+
     def _prep(self):
         """B, D, D^T of the first layer (include/graphmaker_hip.h), recomputed when mlp_in_X.0 has been updated."""
         w, b = self.mlp_in_X[0].weight, self.mlp_in_X[0].bias
@@ -151,10 +176,12 @@ class _TowerBase(nn.Module):
         h_cat = torch.cat(hX_list + hY_list + [h_t_exp], dim=1)
         return mlp2(self.mlp_out, h_cat, False)
 
-    def _run(self, t_float, X_t_one_hot, Y_real, A_t, want_hcat=False, rows=None, out=None, reuse_X=False, x_u8=None):
+    def _run(self, t_float, X_t_one_hot, Y_real, A_t, want_hcat=False, rows=None, out=None, reuse_X=False, x_u8=None,
+             diff_head=False):
         """reuse_X: the caller guarantees that X_t_one_hot, the parameters and the node count are those of the previous
-        fused call of THIS tower, so mlp_in_X(X) is taken from the tower's workspace (ModelAsync's structure steps)."""
-        if self._on_tape() and not want_hcat and rows is None and out is None:
+        fused call of THIS tower, so mlp_in_X(X) is taken from the tower's workspace (ModelAsync's structure steps).
+        diff_head: return the (n, F) logit differences of _head(True) instead of the (n, 2F) logits (sampling only)."""
+        if self._on_tape() and not want_hcat and rows is None and out is None and not diff_head:
             return self._run_tape(t_float, X_t_one_hot, Y_real, A_t)
         if self.training and any(m.p > 0 for m in self.modules() if isinstance(m, nn.Dropout)):
             raise NotImplementedError("the fused tower call has no dropout: use train mode with autograd enabled, or eval()")
@@ -166,12 +193,14 @@ class _TowerBase(nn.Module):
         prep = self._prep()
         reuse = reuse_X and getattr(self, "_hx0_rows", None) == (n, None)
         self._hx0_rows = (n, None)
-        return ops.tower_forward(self._dims, self._param_ptrs(), n, t, None if reuse else X, Y32.contiguous(), A_t, ws,
+        dims, ptrs = self._head(diff_head)
+        return ops.tower_forward(dims, ptrs, n, t, None if reuse else X, Y32.contiguous(), A_t, ws,
                                  want_hcat=want_hcat, rows=rows, out=out, prep=prep, x_u8=None if reuse else x_u8,
                                  sparse_X=self._sparse_X)
 
 
-    def _run_sharded(self, t_float, X_t_one_hot, Y_real, A_t, plan, group, out, gather, reuse_X=False, x_u8=None):
+    def _run_sharded(self, t_float, X_t_one_hot, Y_real, A_t, plan, group, out, gather, reuse_X=False, x_u8=None,
+                     diff_head=False):
         """Row-sharded forward for the one-process-per-GPU decomposition: this rank computes node rows
         plan.node_range() of every stage; before each message-passing layer the [h_X | h_Y] rows of all ranks are
         replicated by `gather` (parallel.all_gather_node_rows).  Writes rows node_range() of `out` (n, out_size)."""
@@ -181,11 +210,13 @@ class _TowerBase(nn.Module):
 
             def wait(self):
                 pass
-        for _ in self._sharded_stages(t_float, X_t_one_hot, Y_real, A_t, plan, group, out, _Now, reuse_X=reuse_X, x_u8=x_u8):
+        for _ in self._sharded_stages(t_float, X_t_one_hot, Y_real, A_t, plan, group, out, _Now, reuse_X=reuse_X, x_u8=x_u8,
+                                      diff_head=diff_head):
             pass
         return out
 
-    def _sharded_stages(self, t_float, X_t_one_hot, Y_real, A_t, plan, group, out, gather_start, reuse_X=False, x_u8=None):
+    def _sharded_stages(self, t_float, X_t_one_hot, Y_real, A_t, plan, group, out, gather_start, reuse_X=False, x_u8=None,
+                        diff_head=False):
         """_run_sharded as a generator: it yields right after each all-gather has been STARTED
         (gather_start(plan, buffer, group) -> handle with .wait(), parallel.start_all_gather_node_rows) and waits for it
         when resumed, so the caller can enqueue other kernels (the other tower's stage) under the transfer."""
@@ -194,7 +225,7 @@ class _TowerBase(nn.Module):
         Y32 = (Y_real if Y_real.dtype == torch.int32 else Y_real.to(torch.int32)).contiguous()
         t = t_float.reshape(1).to(torch.float32)
         dev = X.device
-        d, ptrs, ws = self._dims, self._param_ptrs(), self._workspace(n, dev)
+        (d, ptrs), ws = self._head(diff_head), self._workspace(n, dev)
         prep = self._prep()
         rows = plan.node_range()
         if reuse_X and getattr(self, "_hx0_rows", None) == (n, rows):

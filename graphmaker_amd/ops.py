@@ -350,17 +350,34 @@ def pair_score_sample(h, W1, b1, W2, b2, bits_t, tab, *, seed=0, step=0, u=None,
 
 
 # ------------------------------------------------------------------ attributes
+def head_diff(W, b):
+    """(Wd, bd) of gm_head_diff_prepare: the two-class head mlp_out.2 folded to one logit difference per attribute."""
+    require(W, torch.float32, "W")
+    require(b, torch.float32, "b")
+    F2, Hc = W.shape
+    if F2 % 2 or b.numel() != F2:
+        raise ValueError(f"W is {tuple(W.shape)}, b has {b.numel()} entries: expected (2F, Hc) and 2F")
+    Wd = torch.empty((F2 // 2, Hc), dtype=torch.float32, device=W.device)
+    bd = torch.empty(F2 // 2, dtype=torch.float32, device=W.device)
+    L.call("gm_head_diff_prepare", I64(F2 // 2), I64(Hc), ptr(W), ptr(b), ptr(Wd), ptr(bd), stream_ptr())
+    return Wd, bd
+
+
 def attr_posterior_sample(logits, x_t, tab, *, seed=0, step=0, u=None, want_onehot=True, want_debug=False, rows=None,
-                          x_s=None):
+                          x_s=None, diff=False):
+    """diff=False: logits (n, 2F) / (n, F, 2).  diff=True: logits is the (n, F) difference l1 - l0 of a tower run with the
+    half-width head (gm_attr_posterior_sample_diff)."""
     require(logits, torch.float32, "logits")
     require(x_t, torch.uint8, "x_t")
     require(tab, torch.float32, "tab")
     n, F = x_t.shape
+    if logits.numel() != (1 if diff else 2) * n * F:
+        raise ValueError(f"logits has {logits.numel()} entries, expected {(1 if diff else 2) * n * F} (diff={diff})")
     dev = x_t.device
     x_s = torch.empty_like(x_t) if x_s is None else x_s
     oh = torch.empty((n, 2 * F), dtype=torch.float32, device=dev) if want_onehot else None
     po = torch.empty((n, F, 2), dtype=torch.float32, device=dev) if want_debug else None
-    L.call("gm_attr_posterior_sample", I64(n), I64(F), ptr(logits), ptr(x_t), ptr(tab), ptr(u), U64(seed), U32(step),
+    L.call("gm_attr_posterior_sample_diff" if diff else "gm_attr_posterior_sample", I64(n), I64(F), ptr(logits), ptr(x_t), ptr(tab), ptr(u), U64(seed), U32(step),
            I64(rows[0] if rows else 0), I64(rows[1] if rows else n), ptr(x_s), ptr(oh), ptr(po), stream_ptr())
     res = (x_s, oh)
     return res + (po,) if want_debug else res

@@ -207,6 +207,18 @@ int gm_pair_score_sample_bf16(int64_t n, int64_t hE, const float* h, const float
 int gm_attr_posterior_sample(int64_t n, int64_t F, const float* logits, const uint8_t* x_t, const float* tab,
                              const float* u, uint64_t seed, uint32_t step, int64_t v_begin, int64_t v_end,
                              uint8_t* x_s, float* onehot_out, float* post_dbg, gm_stream_t stream);
+/* The same step from the logit DIFFERENCE diff[v][f] = l1 - l0 (n,F): softmax([l0,l1]) = softmax([0, l1-l0]), the form
+ * the pair kernel uses for the edge classes.  The sampler (model/diffusion.py:875-895) only ever takes the softmax of the
+ * node tower's output, so it runs the tower with the half-width head of gm_head_diff_prepare in place of mlp_out.2
+ * (out_size = F instead of 2F: half of the tower's largest GEMM) and calls this entry.  diff differs from the difference
+ * of the two rounded logits by f32 rounding only (same order as the GEMM's own); the oracle computes it the same way.
+ * Training and forward() keep the two-logit head. */
+int gm_attr_posterior_sample_diff(int64_t n, int64_t F, const float* diff, const uint8_t* x_t, const float* tab,
+                                  const float* u, uint64_t seed, uint32_t step, int64_t v_begin, int64_t v_end,
+                                  uint8_t* x_s, float* onehot_out, float* post_dbg, gm_stream_t stream);
+/* Wd (F,Hc) = W[2f+1] - W[2f], bd (F) = b[2f+1] - b[2f] of mlp_out.2 (W (2F,Hc) row-major, model/gnn.py:139-143):
+ * pass Wd / bd as the last two tower parameters with dims.out_size = F to get diff.  Recompute when W or b change. */
+int gm_head_diff_prepare(int64_t F, int64_t Hc, const float* W, const float* b, float* Wd, float* bd, gm_stream_t stream);
 int gm_onehot_from_x(int64_t n, int64_t F, const uint8_t* x, float* onehot, gm_stream_t stream);
 int gm_x_from_onehot(int64_t n, int64_t F, const float* onehot, uint8_t* x, gm_stream_t stream);
 

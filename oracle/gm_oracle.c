@@ -719,6 +719,53 @@ void gmo_attr_posterior_sample(int64_t n, int64_t F, const float* logits, const 
         }
 }
 
+/* The same step from the logit DIFFERENCE d[v][f] = l1 - l0: softmax([l0, l1]) = softmax([0, d]) (gmo_softmax2_diff, as
+ * the structure denoiser does for the two edge classes).  The product's sampler runs the node tower with the half-width
+ * head of gmo_head_diff and feeds this function; gmo_sample_sync / gmo_sample_async below do the same. */
+void gmo_attr_posterior_sample_diff(int64_t n, int64_t F, const float* diff, const uint8_t* x_t, const float* tab,
+                                    const float* u_or_null, uint64_t seed, uint32_t step, uint8_t* x_s,
+                                    float* post_dbg) {
+#pragma omp parallel for schedule(static)
+    for (int64_t v = 0; v < n; ++v)
+        for (int64_t f = 0; f < F; ++f) {
+            float q0, q1, p0, p1;
+            gmo_softmax2_diff(diff[v * F + f], &q0, &q1);
+            gmo_posterior_apply(tab + 8 * f, (int)x_t[v * F + f], q0, q1, &p0, &p1);
+            int64_t idx = f * n + v;
+            float u = u_or_null ? u_or_null[idx] : u_idx64(seed, step, GMO_STREAM_X, (uint64_t)idx);
+            x_s[v * F + f] = (uint8_t)draw2(u, p0, p1);
+            if (post_dbg) { post_dbg[(v * F + f) * 2] = p0; post_dbg[(v * F + f) * 2 + 1] = p1; }
+        }
+}
+
+/* mlp_out.2 (model/gnn.py:139-143; W (2F,Hc) row-major, b (2F)) folded to one output per attribute:
+ * Wd[f] = W[2f+1] - W[2f], bd[f] = b[2f+1] - b[2f], so that x.Wd[f] + bd[f] = l1 - l0 up to f32 rounding. */
+void gmo_head_diff(int64_t F, int64_t Hc, const float* W, const float* b, float* Wd, float* bd) {
+    for (int64_t f = 0; f < F; ++f) {
+        for (int64_t k = 0; k < Hc; ++k) Wd[f * Hc + k] = W[(2 * f + 1) * Hc + k] - W[2 * f * Hc + k];
+        bd[f] = b[2 * f + 1] - b[2 * f];
+    }
+}
+
+/* a node tower with its head folded by gmo_head_diff: dims/params copies whose last Linear is (F,Hc) */
+typedef struct { gmo_tower_dims d; const float** p; float* Wd; float* bd; } diff_tower;
+static diff_tower diff_tower_make(const gmo_tower_dims* dX, const float* const* pX) {
+    diff_tower t;
+    int np = 9 + 8 * dX->num_layers + 4;
+    int64_t F = dX->out_size / 2, Hc = gmo_tower_hidden_cat(dX);
+    t.d = *dX;
+    t.d.out_size = (int)F;
+    t.p = (const float**)malloc(sizeof(float*) * (size_t)np);
+    memcpy(t.p, pX, sizeof(float*) * (size_t)np);
+    t.Wd = (float*)malloc(sizeof(float) * (size_t)(F * Hc));
+    t.bd = (float*)malloc(sizeof(float) * (size_t)F);
+    gmo_head_diff(F, Hc, pX[np - 2], pX[np - 1], t.Wd, t.bd);
+    t.p[np - 2] = t.Wd;
+    t.p[np - 1] = t.bd;
+    return t;
+}
+static void diff_tower_free(diff_tower* t) { free(t->p); free(t->Wd); free(t->bd); }
+
 void gmo_onehot_from_x(int64_t n, int64_t F, const uint8_t* x, float* oh) {
 #pragma omp parallel for schedule(static)
     for (int64_t v = 0; v < n; ++v)
@@ -779,8 +826,9 @@ void gmo_sample_sync(int T, int64_t n, int64_t F, int C, const float* X_marginal
     gmo_prior_E(n, wpr, E_marginal[0], E_marginal[1], NULL, seed, bits);
     gmo_prior_X(n, F, X_marginal, NULL, seed, x);
 
+    diff_tower tX = diff_tower_make(dX, pX);   /* the sampler's node tower: logit differences (see gmo_head_diff) */
     float* X_oh = (float*)malloc(sizeof(float) * (size_t)(n * 2 * F));
-    float* logits = (float*)malloc(sizeof(float) * (size_t)(n * 2 * F));
+    float* logits = (float*)malloc(sizeof(float) * (size_t)(n * F));
     float* tabX = (float*)malloc(sizeof(float) * (size_t)(8 * F));
     uint32_t* upper = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(n * wpr));
     uint32_t* bits_s = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(n * wpr));
@@ -797,14 +845,15 @@ void gmo_sample_sync(int T, int64_t n, int64_t F, int C, const float* X_marginal
         e_step(n, F, dE, pE, pPair, t_float, X_oh, y, bits, wpr, tabE, seed, (uint32_t)t, as_reference, rowptr,
                &colidx, upper, bits_s);                                  /* :862-872 */
         /* pred_X uses A_t from E_t, not E_s (:875-878); rowptr/colidx still describe E_t */
-        gmo_tower_forward(dX, pX, n, t_float, X_oh, y, rowptr, colidx, logits, NULL);
+        gmo_tower_forward(&tX.d, tX.p, n, t_float, X_oh, y, rowptr, colidx, logits, NULL);
         gmo_posterior_tables_X(F, X_marginal, alphas[t], abars[t - 1], abars[t], tabX);   /* :889-891 */
-        gmo_attr_posterior_sample(n, F, logits, x, tabX, NULL, seed, (uint32_t)t, x_s, NULL);
+        gmo_attr_posterior_sample_diff(n, F, logits, x, tabX, NULL, seed, (uint32_t)t, x_s, NULL);
         memcpy(x, x_s, (size_t)(n * F));
         memcpy(bits, bits_s, sizeof(uint32_t) * (size_t)(n * wpr));     /* :896 */
     }
     free(betas); free(X_oh); free(logits); free(tabX); free(upper); free(bits_s); free(x_s);
     free(rowptr); free(colidx);
+    diff_tower_free(&tX);
 }
 
 void gmo_sample_async(int T_X, int T_E, int64_t n, int64_t F, int C, const float* X_marginal,
@@ -829,17 +878,18 @@ void gmo_sample_async(int T_X, int T_E, int64_t n, int64_t F, int C, const float
     gmo_prior_Y(n, C, Y_marginal, NULL, seed, y);                       /* :1319-1321 */
     gmo_prior_X(n, F, X_marginal, NULL, seed, x);                       /* :1325-1327 */
 
+    diff_tower tX = diff_tower_make(dX, pX);
     float* X_oh = (float*)malloc(sizeof(float) * (size_t)(n * 2 * F));
-    float* logits = (float*)malloc(sizeof(float) * (size_t)(n * 2 * F));
+    float* logits = (float*)malloc(sizeof(float) * (size_t)(n * F));
     float* tabX = (float*)malloc(sizeof(float) * (size_t)(8 * F));
     uint8_t* x_s = (uint8_t*)malloc((size_t)(n * F));
     for (int s = T_X - 1; s >= 0; --s) {                                /* :1330-1358 */
         int t = s + 1;
         float t_float = (float)((double)t / (double)T_X);
         gmo_onehot_from_x(n, F, x, X_oh);
-        gmo_tower_forward(dX, pX, n, t_float, X_oh, y, NULL, NULL, logits, NULL);
+        gmo_tower_forward(&tX.d, tX.p, n, t_float, X_oh, y, NULL, NULL, logits, NULL);
         gmo_posterior_tables_X(F, X_marginal, aX[t], abX[t - 1], abX[t], tabX);
-        gmo_attr_posterior_sample(n, F, logits, x, tabX, NULL, seed, (uint32_t)t, x_s, NULL);
+        gmo_attr_posterior_sample_diff(n, F, logits, x, tabX, NULL, seed, (uint32_t)t, x_s, NULL);
         memcpy(x, x_s, (size_t)(n * F));
     }
     gmo_prior_E(n, wpr, E_marginal[0], E_marginal[1], NULL, seed, bits); /* :1362-1365 */
@@ -859,4 +909,5 @@ void gmo_sample_async(int T_X, int T_E, int64_t n, int64_t F, int C, const float
     }
     free(sx); free(X_oh); free(logits); free(tabX); free(x_s); free(upper); free(bits_s);
     free(rowptr); free(colidx);
+    diff_tower_free(&tX);
 }

@@ -135,6 +135,11 @@ void gmo_pair_score_sample(int64_t n, int64_t hE, const float* h, const float* W
 void gmo_attr_posterior_sample(int64_t n, int64_t F, const float* logits /* (n,F,2) */,
                                const uint8_t* x_t, const float* tab /* F*8 */, const float* u_or_null,
                                uint64_t seed, uint32_t step, uint8_t* x_s, float* post_dbg /* (n,F,2) */);
+/* the same from the logit difference diff (n,F) = l1 - l0, and the head folding that produces it (see gm_oracle.c) */
+void gmo_attr_posterior_sample_diff(int64_t n, int64_t F, const float* diff /* (n,F) */, const uint8_t* x_t,
+                                    const float* tab, const float* u_or_null, uint64_t seed, uint32_t step,
+                                    uint8_t* x_s, float* post_dbg /* (n,F,2) */);
+void gmo_head_diff(int64_t F, int64_t Hc, const float* W, const float* b, float* Wd, float* bd);
 void gmo_onehot_from_x(int64_t n, int64_t F, const uint8_t* x, float* oh);
 /* first tower layer on exactly-one-hot attributes, evaluated as base + corrections (see gm_oracle.c) */
 void gmo_onehot_linear(int64_t n, int64_t F, int64_t H, const float* X_one_hot, const float* W, const float* b,

@@ -326,7 +326,22 @@ class Tower:
                          out_size=params[-2].shape[0], is_mlp=int(is_mlp))
         return Tower(dims, params)
 
-    def forward(self, t_float, X_one_hot, Y, rowptr=None, colidx=None, want_hcat=False):
+    def diff_head(self):
+        """This tower with mlp_out.2 folded to the logit difference l1 - l0 per attribute (gmo_head_diff): the node tower
+        as the sampler runs it (out_size F instead of 2F)."""
+        if getattr(self, "_diff", None) is None:
+            d = self.dims
+            F, Hc = d.out_size // 2, d.hidden_cat
+            Wd, bd = np.empty((F, Hc), np.float32), np.empty(F, np.float32)
+            lib().gmo_head_diff(C.c_int64(F), C.c_int64(Hc), _p(self.params[-2]), _p(self.params[-1]), _p(Wd), _p(bd))
+            dims = TowerDims(in_X=d.in_X, num_classes_Y=d.num_classes_Y, hidden_t=d.hidden_t, hidden_X=d.hidden_X,
+                             hidden_Y=d.hidden_Y, num_layers=d.num_layers, out_size=F, is_mlp=d.is_mlp)
+            self._diff = Tower(dims, self.params[:-2] + [Wd, bd])
+        return self._diff
+
+    def forward(self, t_float, X_one_hot, Y, rowptr=None, colidx=None, want_hcat=False, diff_head=False):
+        if diff_head:
+            return self.diff_head().forward(t_float, X_one_hot, Y, rowptr, colidx, want_hcat)
         X = f32(X_one_hot)
         n = X.shape[0]
         Y = np.ascontiguousarray(Y, np.int32)
@@ -364,14 +379,16 @@ def pair_score_sample(n, h, pair, bits_t, tab, u=None, seed=0, step=0, row_begin
     return (out, lg, po) if want_debug else out
 
 
-def attr_posterior_sample(logits, x_t, tab, u=None, seed=0, step=0, want_debug=False):
+def attr_posterior_sample(logits, x_t, tab, u=None, seed=0, step=0, want_debug=False, diff=False):
+    """diff: `logits` is the (n, F) difference l1 - l0 of a tower run with diff_head (gmo_attr_posterior_sample_diff)."""
     x_t = np.ascontiguousarray(x_t, np.uint8)
     n, F = x_t.shape
-    logits = f32(logits).reshape(n, F, 2)
+    logits = f32(logits).reshape((n, F) if diff else (n, F, 2))
     x_s = np.empty((n, F), np.uint8)
     po = np.empty((n, F, 2), np.float32) if want_debug else None
-    lib().gmo_attr_posterior_sample(C.c_int64(n), C.c_int64(F), _p(logits), _p(x_t), _p(f32(tab)), _p(u),
-                                    C.c_uint64(seed), C.c_uint32(step), _p(x_s), _p(po))
+    fn = lib().gmo_attr_posterior_sample_diff if diff else lib().gmo_attr_posterior_sample
+    fn(C.c_int64(n), C.c_int64(F), _p(logits), _p(x_t), _p(f32(tab)), _p(u), C.c_uint64(seed), C.c_uint32(step), _p(x_s),
+       _p(po))
     return (x_s, po) if want_debug else x_s
 
 

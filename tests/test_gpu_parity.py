@@ -470,6 +470,25 @@ def test_attribute_step_vs_reference_and_oracle(dev, name):
         x_p, _ = ops.attr_posterior_sample(ref_logits, t_(x_in, dev), t_(tab, dev), seed=seed, step=t)
         np.testing.assert_array_equal(x_p.cpu().numpy(), o_x)
         np.testing.assert_array_equal(x_s.cpu().numpy(), g[f"x{t}_X_out"])
+        # the sampler's form: tower with the head folded to l1 - l0 (gm_head_diff_prepare), softmax from the difference
+        pred_X = model.graph_encoder.pred_X
+        diff = pred_X._run(t_float, X_oh, Y32, A_t if sync else None, diff_head=True)
+        assert tuple(diff.shape) == (N, F)
+        o_diff = towerX.forward(np.float32(t / T), X_oh.cpu().numpy(), g["Y"], *((rp, ci) if sync else ()), diff_head=True)
+        check_float(diff, o_diff, LOGIT_ATOL, "attribute tower, logit-difference head")
+        ref_diff = g[f"x{t}_X_logits"][:, :, 1] - g[f"x{t}_X_logits"][:, :, 0]
+        np.testing.assert_allclose(diff.cpu().numpy(), ref_diff, atol=2 * LOGIT_ATOL, rtol=RTOL)
+        x_d, oh_d, po_d = ops.attr_posterior_sample(t_(ref_diff, dev), t_(x_in, dev), t_(tab, dev), u=t_(u, dev), want_debug=True,
+                                                    diff=True)
+        np.testing.assert_allclose(po_d.cpu().numpy(), ref_prob, atol=POST_ATOL, rtol=RTOL)
+        o_xd, o_pod = orc.attr_posterior_sample(ref_diff, x_in, tab, u=u, want_debug=True, diff=True)
+        check_float(po_d, o_pod, POST_ATOL, "attribute posteriors from the logit difference")
+        np.testing.assert_array_equal(x_d.cpu().numpy(), o_xd)
+        np.testing.assert_array_equal(oh_d.cpu().numpy(), orc.onehot_from_x(o_xd))
+        np.testing.assert_array_equal(x_d.cpu().numpy(), g[f"x{t}_X_out"])
+        x_m, _ = (model.denoise_step(t, t_(x_in, dev), X_oh, Y32, bits_t(ref_bits, dev), seed)[:2] if sync
+                  else model.attribute_step(t, t_(x_in, dev), X_oh, Y32, seed))
+        np.testing.assert_array_equal(x_m.cpu().numpy(), orc.attr_posterior_sample(o_diff, x_in, tab, seed=seed, step=t, diff=True))
 
 
 @pytest.mark.parametrize("name", ["sync_small", "sync_mid", "async_mid", "async_T6", "async_wide"])
@@ -712,8 +731,8 @@ def test_rank_shards_reproduce_single_gpu_step(dev, world):
     W1, b1, W2, b2 = model.graph_encoder.pred_E.pair_params()
     h_full = enc(t_float, X_oh, Y32, A_t)
     up_full = ops.pair_score_sample(h_full, W1, b1, W2, b2, bits, tab_E, seed=seed, step=T)
-    lg_full = pred_X._run(t_float, X_oh, Y32, A_t)
-    xs_full, _ = ops.attr_posterior_sample(lg_full, x_in, t_(tab_X, dev), seed=seed, step=T)
+    lg_full = pred_X._run(t_float, X_oh, Y32, A_t, diff_head=True)          # the sampler's half-width head: l1 - l0
+    xs_full, _ = ops.attr_posterior_sample(lg_full, x_in, t_(tab_X, dev), seed=seed, step=T, diff=True)
 
     h = torch.full_like(h_full, float("nan"))
     up = torch.zeros_like(up_full)
@@ -721,9 +740,9 @@ def test_rank_shards_reproduce_single_gpu_step(dev, world):
     xs = torch.full_like(xs_full, 255)
     plans = [ShardPlan.make(N, world, r) for r in range(world)]
 
-    def staged(tower, out):
+    def staged(tower, out, diff_head=False):
         # every stage is run for each rank's rows in turn; the shared buffers play the part of the all-gathers
-        d, ptrs, ws = tower._dims, tower._param_ptrs(), tower._workspace(N, dev)
+        (d, ptrs), ws = tower._head(diff_head), tower._workspace(N, dev)
         bufs = [torch.full((N, d.hidden_X + d.hidden_Y), float("nan"), device=dev) for _ in range(2)]
         for pl in plans:
             ops.tower_stage(d, ptrs, N, -1, pl.node_range(), ws, t_float=t_float, X_one_hot=X_oh, Y32=Y32, layer_dst=bufs[0],
@@ -736,13 +755,13 @@ def test_rank_shards_reproduce_single_gpu_step(dev, world):
             ops.tower_stage(d, ptrs, N, d.num_layers, pl.node_range(), ws, out=out)
 
     staged(enc, h)
-    staged(pred_X, lg)
+    staged(pred_X, lg, diff_head=True)
     assert torch.equal(h, h_full) and torch.equal(lg, lg_full)
     for r in range(world):
         plan = ShardPlan.make(N, world, r)
         ops.pair_score_sample(h, W1, b1, W2, b2, bits, tab_E, seed=seed, step=T, row_ranges=plan.pair_chunks(), out_upper=up)
         ops.attr_posterior_sample(lg, x_in, t_(tab_X, dev), seed=seed, step=T, rows=plan.node_range(), x_s=xs,
-                                  want_onehot=False)
+                                  want_onehot=False, diff=True)
     assert torch.equal(ops.symmetrize_upper(up, N), ops.symmetrize_upper(up_full, N))
     assert torch.equal(xs, xs_full)
 
@@ -806,9 +825,10 @@ def test_full_size_step_properties_and_oracle_bands(dev, n, F, ht):
     np.testing.assert_array_equal(bits_np(ops.symmetrize_upper(t_(up.view(np.int32), dev), n)), bits_np(bits1))
     # attribute draw: oracle on the GPU's logits (bit-exact), in-kernel Philox == host-supplied uniforms
     logits = model.graph_encoder.pred_X._run(t_float, oh, Y32, A_t)
-    o_x = orc.attr_posterior_sample(logits.cpu().numpy(), x.cpu().numpy(), tab_X, seed=seed, step=t)
+    diff = model.graph_encoder.pred_X._run(t_float, oh, Y32, A_t, diff_head=True)      # what the step's draw reads
+    o_x = orc.attr_posterior_sample(diff.cpu().numpy(), x.cpu().numpy(), tab_X, seed=seed, step=t, diff=True)
     np.testing.assert_array_equal(x1.cpu().numpy(), o_x)
-    x_u, _ = ops.attr_posterior_sample(logits, x, t_(tab_X, dev), u=t_(orc.uniform_X(seed, t, n, F), dev))
+    x_u, _ = ops.attr_posterior_sample(diff, x, t_(tab_X, dev), u=t_(orc.uniform_X(seed, t, n, F), dev), diff=True)
     np.testing.assert_array_equal(x_u.cpu().numpy(), o_x)
     # both towers on ALL nodes against the oracle, bit for bit (at 13752 nodes this is the only place where the XCD-sliced
     # SpMM and the 128x128 GEMM configuration are compared with the oracle inside the step the bench times)
@@ -818,6 +838,8 @@ def test_full_size_step_properties_and_oracle_bands(dev, n, F, ht):
     rp, ci = orc.csr_from_bitmap(bits_host, n)
     check_float(h, towerE.forward(np.float32(1.0), oh.cpu().numpy(), Y32.cpu().numpy(), rp, ci), LOGIT_ATOL, "edge tower, full size")
     check_float(logits, towerX.forward(np.float32(1.0), oh.cpu().numpy(), Y32.cpu().numpy(), rp, ci), LOGIT_ATOL, "node tower, full size")
+    check_float(diff, towerX.forward(np.float32(1.0), oh.cpu().numpy(), Y32.cpu().numpy(), rp, ci, diff_head=True), LOGIT_ATOL,
+                "node tower with the logit-difference head, full size")
 
 
 def test_eight_rank_shards_reproduce_single_gpu_step_at_amazon_computer_size(dev):
@@ -851,8 +873,8 @@ def test_eight_rank_shards_reproduce_single_gpu_step_at_amazon_computer_size(dev
     W1, b1, W2, b2 = model.graph_encoder.pred_E.pair_params()
     h_full = enc(t_float, X_oh, Y32, A_t)
     up_full = ops.pair_score_sample(h_full, W1, b1, W2, b2, bits, tab_E, seed=seed, step=T)
-    lg_full = pred_X._run(t_float, X_oh, Y32, A_t).clone()
-    xs_full, _ = ops.attr_posterior_sample(lg_full, x_in, t_(tab_X, dev), seed=seed, step=T)
+    lg_full = pred_X._run(t_float, X_oh, Y32, A_t, diff_head=True).clone()
+    xs_full, _ = ops.attr_posterior_sample(lg_full, x_in, t_(tab_X, dev), seed=seed, step=T, diff=True)
     x1, _, bits1 = model.denoise_step(T, x_in, X_oh, Y32, bits, seed)            # the step the bench times
     assert torch.equal(x1, xs_full) and torch.equal(bits1, ops.symmetrize_upper(up_full, n))
 
@@ -863,8 +885,8 @@ def test_eight_rank_shards_reproduce_single_gpu_step_at_amazon_computer_size(dev
     xs = torch.full_like(xs_full, 255)
     up = torch.zeros((plans[0].padded_pair_rows, up_full.shape[1]), dtype=torch.int32, device=dev)
 
-    def staged(tower, out):
-        d, ptrs, ws = tower._dims, tower._param_ptrs(), tower._workspace(n, dev)
+    def staged(tower, out, diff_head=False):
+        (d, ptrs), ws = tower._head(diff_head), tower._workspace(n, dev)
         bufs = [torch.full((n, d.hidden_X + d.hidden_Y), float("nan"), device=dev) for _ in range(2)]
         for pl in plans:
             ops.tower_stage(d, ptrs, n, -1, pl.node_range(), ws, t_float=t_float, X_one_hot=X_oh, Y32=Y32, layer_dst=bufs[0],
@@ -877,11 +899,12 @@ def test_eight_rank_shards_reproduce_single_gpu_step_at_amazon_computer_size(dev
             ops.tower_stage(d, ptrs, n, d.num_layers, pl.node_range(), ws, out=out)
 
     staged(enc, h)
-    staged(pred_X, lg)
+    staged(pred_X, lg, diff_head=True)
     assert torch.equal(h, h_full) and torch.equal(lg, lg_full)
     for pl in plans:
         ops.pair_score_sample(h, W1, b1, W2, b2, bits, tab_E, seed=seed, step=T, row_ranges=pl.pair_chunks(), out_upper=up)
-        ops.attr_posterior_sample(lg, x_in, t_(tab_X, dev), seed=seed, step=T, rows=pl.node_range(), x_s=xs, want_onehot=False)
+        ops.attr_posterior_sample(lg, x_in, t_(tab_X, dev), seed=seed, step=T, rows=pl.node_range(), x_s=xs, want_onehot=False,
+                                  diff=True)
     assert torch.equal(ops.symmetrize_upper(up[:n].contiguous(), n), bits1)
     assert torch.equal(xs, xs_full)
 
@@ -915,7 +938,10 @@ def test_amazon_computer_async_attribute_tower_hidden_1024(dev):
     towerX = orc.Tower.from_state_dict(sdX, is_mlp=True)
     o_logits = towerX.forward(np.float32(t / 7), oh.cpu().numpy(), Y32.cpu().numpy())
     check_float(logits.reshape(n, 2 * F), o_logits, LOGIT_ATOL, "MLPTower hidden_X=1024 at N=13752")
-    o_x = orc.attr_posterior_sample(o_logits, x.cpu().numpy(), model.table_X(t), seed=seed, step=t)
+    o_diff = towerX.forward(np.float32(t / 7), oh.cpu().numpy(), Y32.cpu().numpy(), diff_head=True)
+    check_float(model.graph_encoder.pred_X._run(t_float, oh, Y32, None, diff_head=True), o_diff, LOGIT_ATOL,
+                "MLPTower hidden_X=1024, logit-difference head")
+    o_x = orc.attr_posterior_sample(o_diff, x.cpu().numpy(), model.table_X(t), seed=seed, step=t, diff=True)
     np.testing.assert_array_equal(x_s.cpu().numpy(), o_x)
     np.testing.assert_array_equal(oh_s.cpu().numpy(), orc.onehot_from_x(o_x))
 
@@ -975,10 +1001,15 @@ def test_sbm100k_full_sync_step_against_the_oracle(dev):
     logits = model.graph_encoder.pred_X._run(t_float, oh, Y32, A_t)
     o_logits = towerX.forward(np.float32(1.0), oh_np, y_np, rp, ci)
     check_float(logits, o_logits, LOGIT_ATOL, "node tower at N=100k")
-    del logits, oh_np
+    del logits, o_logits
+    o_diff = towerX.forward(np.float32(1.0), oh_np, y_np, rp, ci, diff_head=True)       # what the step's draw reads
+    check_float(model.graph_encoder.pred_X._run(t_float, oh, Y32, A_t, diff_head=True), o_diff, LOGIT_ATOL,
+                "node tower with the logit-difference head at N=100k")
+    del oh_np
     tab_E, tab_X = model.step_tables(t)
-    np.testing.assert_array_equal(x1.cpu().numpy(), orc.attr_posterior_sample(o_logits, x.cpu().numpy(), tab_X, seed=seed, step=t))
-    del o_logits
+    np.testing.assert_array_equal(x1.cpu().numpy(),
+                                  orc.attr_posterior_sample(o_diff, x.cpu().numpy(), tab_X, seed=seed, step=t, diff=True))
+    del o_diff
     # pair rows: the step's E_s (symmetrised) against oracle bands computed from the oracle's h
     got = bits_np(bits1)
     nw = (n + 31) // 32
@@ -1087,8 +1118,8 @@ def test_cora_size_steps_and_sample_against_the_reference(dev):
         if len(v):
             _, tab_X = model.step_tables(t)
             t_float = torch.tensor([t / T], dtype=torch.float32, device=dev)
-            logits = model.graph_encoder.pred_X._run(t_float, oh_in, Y32, ops.adjacency_from_bitmap(bits_in, N))
-            _, _, pX = ops.attr_posterior_sample(logits, x_in, t_(tab_X, dev), seed=seed, step=t, want_debug=True)
+            diff = model.graph_encoder.pred_X._run(t_float, oh_in, Y32, ops.adjacency_from_bitmap(bits_in, N), diff_head=True)
+            _, _, pX = ops.attr_posterior_sample(diff, x_in, t_(tab_X, dev), seed=seed, step=t, want_debug=True, diff=True)
             pX = pX.cpu().numpy()[v, f]
             u = orc.uniform_X(seed, t, N, F)[f * N + v]
             far = np.abs(u * (pX[:, 0] + pX[:, 1]) - pX[:, 1]) > KNIFE
