@@ -263,12 +263,16 @@ extern "C" int gm_linear(int64_t M, int64_t N, int64_t K, const float* A, int64_
             if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
             else cus = 256;
         }
-        // useful outputs / outputs computed over whole rounds of the grid (tile padding and the partly empty last round)
+        // useful outputs / outputs computed over whole rounds of the chip (tile padding and the partly empty last round).
+        // The 8-wave tile runs two workgroups per CU that share the CU's matrix pipe, so its rounds are counted per CU
+        // like the 16-wave tile's (a CU left with one workgroup finishes it in about half the time): 6876 x 1744 is 756 tiles
+        // of 128x128 = 2.95 per CU (0.357 ms) but 378 of 128x256 = 1.48 per CU (0.438 ms).  Per tile the 16-wave kernel is
+        // ~8% faster (124 vs 113 TFLOP/s at 13752x1744x1744), hence the 0.92.
         const int64_t tiles256 = ((N + 255) / 256) * ((M + 127) / 128);
         const double useful = (double)M * (double)N;
         const double eff16 = useful / ((double)(((tiles256 + cus - 1) / cus) * cus) * 128.0 * 256.0);
-        const double eff8 = useful / ((double)(((tiles128 + 2 * cus - 1) / (2 * cus)) * 2 * cus) * 128.0 * 128.0);
-        if (eff16 >= 0.95 * eff8) return launch_linear<2, 4, 32, 1, 4, 4>(M, N, K, A, lda, W, ldw, bias, C, ldc, relu, s);
+        const double eff8 = 0.92 * useful / ((double)(((tiles128 + cus - 1) / cus) * cus) * 128.0 * 128.0);
+        if (eff16 >= eff8) return launch_linear<2, 4, 32, 1, 4, 4>(M, N, K, A, lda, W, ldw, bias, C, ldc, relu, s);
         return launch_linear<2, 4, 32, 2, 4, 2>(M, N, K, A, lda, W, ldw, bias, C, ldc, relu, s);
     }
     // few 64x64 tiles (a rank's row block, Cora-sized graphs, the 128- and 64-wide layers): the serial K walk of one

@@ -502,8 +502,8 @@ class ModelSync(BaseModel):
     def _denoise_step_sharded(self, t, t_float, x, x_onehot, Y32, bits_t, tab_E, tab_X, seed, uE, uX, plan, group):
         """denoise_step on one rank of the one-process-per-GPU decomposition (parallel.py), scheduled so that the
         transfers hide under compute.  Both towers read the same A_t / X_t / Y (the attribute tower uses A_t of E_t,
-        model/diffusion.py:875-878), so their row-sharded stages are issued alternately: while the [h_X | h_Y] rows of
-        one tower's stage are on the wire, the other tower's stage computes.  The attribute draw runs before the pair
+        model/diffusion.py:875-878), so their row-sharded stages are issued alternately, each tower on its own stream:
+        while the [h_X | h_Y] rows of one tower's stage are on the wire, the other tower's stage computes.  The attribute draw runs before the pair
         kernel and its all-gather travels under it.  Every rank issues the collectives in the same order.  Draws are
         keyed on global indices, so the result is bit-identical to the single-GPU step."""
         n, dev = self.num_nodes, x.device
@@ -515,20 +515,30 @@ class ModelSync(BaseModel):
         logits = self._buf("logit_diff", (n, self.num_attrs_X), torch.float32, dev)      # l1 - l0 per attribute (_logits_fn)
         x_pad = self._buf("x_pad", (plan.world * plan.node_rows, x.shape[1]), torch.uint8, dev)
         start = parallel.start_all_gather_node_rows
-        with self.phase("towers"):
-            stages = [enc._sharded_stages(t_float, x_onehot, Y32, A_t, plan, group, h_pad[:n], start, x_u8=x),
-                      pred_X._sharded_stages(t_float, x_onehot, Y32, A_t, plan, group, logits, start, x_u8=x, diff_head=True)]
+        # A rank's row block is small (1719 rows at 8 ranks: most GEMMs of a stage are a few hundred workgroups), so each
+        # tower gets its own stream and the stages of the two fill the chip together, as on a single GPU.  The host still
+        # issues the stages alternately, which fixes the order of the collectives on every rank; an all-gather waits for
+        # the stream it was started from, and its tower's next stage waits for it on that stream.
+        cur, side = torch.cuda.current_stream(dev), self._side_stream(dev)
+        with self.phase("towers"):                                   # CSR done -> both towers and the attribute draw done
+            side.wait_stream(cur)
+            stages = [(enc._sharded_stages(t_float, x_onehot, Y32, A_t, plan, group, h_pad[:n], start, x_u8=x), cur),
+                      (pred_X._sharded_stages(t_float, x_onehot, Y32, A_t, plan, group, logits, start, x_u8=x, diff_head=True),
+                       side)]
             while stages:
-                for g in list(stages):
+                for item in list(stages):
                     try:
-                        next(g)
+                        with torch.cuda.stream(item[1]):
+                            next(item[0])
                     except StopIteration:
-                        stages.remove(g)
-        h_on_wire = start(plan, h_pad, group)                        # node embeddings of every rank (pair kernel input)
-        with self.phase("attr"):                                     # ... while this rank draws its attribute rows
-            ops.attr_posterior_sample(logits, x, self._const(("tab_X", t, tab_X.tobytes()), tab_X, dev), seed=seed, step=t, u=uX,
-                                      rows=plan.node_range(), x_s=x_pad[:n], want_onehot=False, diff=True)
-        x_on_wire = start(plan, x_pad, group)                        # travels under the pair kernel
+                        stages.remove(item)
+            h_on_wire = start(plan, h_pad, group)                    # node embeddings of every rank (pair kernel input)
+            with torch.cuda.stream(side):                            # ... while this rank draws its attribute rows
+                with self.phase("attr"):
+                    ops.attr_posterior_sample(logits, x, self._const(("tab_X", t, tab_X.tobytes()), tab_X, dev), seed=seed, step=t,
+                                              u=uX, rows=plan.node_range(), x_s=x_pad[:n], want_onehot=False, diff=True)
+                x_on_wire = start(plan, x_pad, group)                # travels under the pair kernel
+            cur.wait_stream(side)                                    # the pair kernel takes the whole chip: join first
         with self.phase("allgather_h"):
             h_on_wire.wait()
         h = h_pad[:n]

@@ -9,7 +9,7 @@ MS = [13752]
 if argv and argv[0] == "--m":
     MS = [int(x) for x in argv[1].split(",")]
     argv = argv[2:]
-SHAPES = [(M, n, k) for M in MS for (n, k) in [(512, 1534), (512, 512), (512, 592), (1744, 1744), (128, 1744), (1534, 1744), (64, 64)]]
+SHAPES = [(M, n, k) for M in MS for (n, k) in [(512, 1534), (512, 512), (512, 592), (1744, 1744), (128, 1744), (1534, 1744), (767, 1744), (64, 64)]]
 libs = [(p, C.CDLL(os.path.join(ROOT, p))) for p in argv]
 tot = {p: 0.0 for p, _ in libs}
 for (M, N, K) in SHAPES:
