@@ -491,6 +491,57 @@ def test_attribute_step_vs_reference_and_oracle(dev, name):
         np.testing.assert_array_equal(x_m.cpu().numpy(), orc.attr_posterior_sample(o_diff, x_in, tab, seed=seed, step=t, diff=True))
 
 
+@pytest.mark.parametrize("F,Hc", [(1, 1), (3, 5), (767, 1744), (130, 33)])
+def test_head_diff_prepare_matches_the_oracle(dev, F, Hc):
+    """gm_head_diff_prepare: Wd = W[2f+1] - W[2f], bd = b[2f+1] - b[2f], bit for bit (exact f32 subtractions)."""
+    ops = _ops()
+    rs = np.random.RandomState(F * 131 + Hc)
+    W = rs.standard_normal((2 * F, Hc)).astype(np.float32)
+    b = rs.standard_normal(2 * F).astype(np.float32)
+    Wd, bd = ops.head_diff(t_(W, dev), t_(b, dev))
+    np.testing.assert_array_equal(Wd.cpu().numpy(), W[1::2] - W[0::2])
+    np.testing.assert_array_equal(bd.cpu().numpy(), b[1::2] - b[0::2])
+    with pytest.raises(ValueError):
+        ops.head_diff(t_(W[:-1].copy(), dev), t_(b[:-1].copy(), dev)) if F > 1 else ops.head_diff(t_(W, dev), t_(b[:1].copy(), dev))
+
+
+def test_folded_attribute_head_follows_weight_updates(dev):
+    """The sampler's folded head (gnn._TowerBase._head) is cached per version of mlp_out.2: an in-place update (optimizer
+    step), load_state_dict and a changed first layer must all reach the next attribute step."""
+    ops = _ops()
+    cfg, g, model, towerX, *_ = _models("async_mid", dev)
+    N, F, seed, T = cfg["N"], cfg["F"], cfg["seed"], cfg["T_X"]
+    pred_X = model.graph_encoder.pred_X
+    Y32 = t_(g["Y"], dev)
+    x_in = g[f"x{T}_X_in"]
+    X_oh = t_(orc.onehot_from_x(x_in), dev)
+    t_float = torch.tensor([1.0], dtype=torch.float32, device=dev)
+
+    def check(what):
+        sd = {k: v.detach().cpu().numpy() for k, v in pred_X.state_dict().items()}
+        want = orc.Tower.from_state_dict(sd, is_mlp=True).forward(np.float32(1.0), X_oh.cpu().numpy(), g["Y"], diff_head=True)
+        check_float(pred_X._run(t_float, X_oh, Y32, None, diff_head=True), want, LOGIT_ATOL, what)
+        return want
+
+    d0 = check("folded head, checkpoint weights")
+    with torch.no_grad():
+        pred_X.mlp_out[2].bias[1::2] += 0.5                      # in place: same storage, new version
+    d1 = check("folded head after an in-place bias update")
+    assert np.abs(d1 - d0 - 0.5).max() < 1e-4
+    with torch.no_grad():
+        pred_X.mlp_out[2].weight.mul_(0.5)
+    check("folded head after an in-place weight update")
+    sd = {k: v.clone() for k, v in pred_X.state_dict().items()}
+    sd["mlp_out.2.weight"] = sd["mlp_out.2.weight"] * -2.0
+    sd["mlp_in_X.0.bias"] = sd["mlp_in_X.0.bias"] + 0.25
+    pred_X.load_state_dict(sd)
+    d3 = check("folded head after load_state_dict")
+    x_s, _ = model.attribute_step(T, t_(x_in, dev), X_oh, Y32, seed)
+    np.testing.assert_array_equal(x_s.cpu().numpy(), orc.attr_posterior_sample(d3, x_in, model.table_X(T), seed=seed, step=T, diff=True))
+    logits = pred_X(t_float, X_oh, Y32)                                          # the two-logit head is untouched by all this
+    np.testing.assert_allclose((logits[:, :, 1] - logits[:, :, 0]).cpu().numpy(), d3, atol=2 * LOGIT_ATOL, rtol=RTOL)
+
+
 @pytest.mark.parametrize("name", ["sync_small", "sync_mid", "async_mid", "async_T6", "async_wide"])
 def test_sample_matches_reference_trajectory(dev, name):
     cfg, g, model, *_ = _models(name, dev)
