@@ -12,30 +12,49 @@
 namespace gm {
 
 // DIFF: `logits` is (n,F), the difference l1 - l0 per attribute (softmax([l0,l1]) = softmax([0,d]), as in the pair kernel)
+// grid: x = group of four nodes, y = 256-attribute chunk (lanes run over attributes: every access is a coalesced row piece).
+// The draw of (v,f) is word idx&3 of the Philox block idx>>2, idx = f*n + v (reshape(-1, 2) of the (F, n, 2) tensor,
+// model/diffusion.py:228-230), so a thread takes the four nodes v = 4*q' - s + k, s = (f*n)&3, whose indices share one
+// block: one Philox call per four draws instead of four (the kernel was bound by its integer multiplies).
 template <bool DIFF>
 __global__ void k_attr_posterior_sample(int64_t n, int64_t F, const float* __restrict__ logits,
                                         const uint8_t* __restrict__ x_t, const float* __restrict__ tab,
                                         const float* __restrict__ u, uint64_t seed, uint32_t step, int64_t v_begin,
                                         int64_t v_end, uint8_t* __restrict__ x_s, float* __restrict__ onehot,
                                         float* __restrict__ post) {
-    // grid: x = node row, y = 256-attribute chunk (no 64-bit division per element)
-    const int64_t v = v_begin + blockIdx.x, f = (int64_t)blockIdx.y * blockDim.x + threadIdx.x;
+    const int64_t f = (int64_t)blockIdx.y * blockDim.x + threadIdx.x;
     if (f >= F) return;
-    const int64_t g = v * F + f;
-    float q0, q1, p0, p1;
-    if (DIFF) {
-        softmax2_diff(logits[g], q0, q1);
-    } else {
-        const float2 l = *reinterpret_cast<const float2*>(logits + 2 * g);
-        softmax2(l.x, l.y, q0, q1);
+    const int64_t base = f * n, s = base & 3;
+    const int64_t v0 = ((v_begin >> 2) + (int64_t)blockIdx.x) * 4 - s;
+    u32x4 o;
+    if (!u) {
+        const uint64_t q = (uint64_t)(base + v0) >> 2;            // base + v0 is a multiple of 4 (and >= 0 where a v is valid)
+        o = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), step, STREAM_X, (uint32_t)seed, (uint32_t)(seed >> 32));
     }
-    posterior2(tab + 8 * f, (int)x_t[g], q0, q1, p0, p1);
-    const int64_t idx = f * n + v;   // reshape(-1, 2) of the (F, n, 2) tensor, model/diffusion.py:228-230
-    const float uu = u ? u[idx] : u_idx64(seed, step, STREAM_X, (uint64_t)idx);
-    const bool b = draw2(uu, p0, p1);
-    x_s[g] = b ? 1 : 0;
-    if (onehot) *reinterpret_cast<float2*>(onehot + 2 * g) = b ? make_float2(0.f, 1.f) : make_float2(1.f, 0.f);
-    if (post) *reinterpret_cast<float2*>(post + 2 * g) = make_float2(p0, p1);
+    const float* tf = tab + 8 * f;                                // this attribute's posterior table, once for the four nodes
+    const float t0 = tf[0], t1 = tf[1], t2 = tf[2], t3 = tf[3], t4 = tf[4], t5 = tf[5], t6 = tf[6], t7 = tf[7];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t v = v0 + k;
+        if (v < v_begin || v >= v_end) continue;
+        const int64_t g = v * F + f;
+        float q0, q1, p0, p1;
+        if (DIFF) {
+            softmax2_diff(logits[g], q0, q1);
+        } else {
+            const float2 l = *reinterpret_cast<const float2*>(logits + 2 * g);
+            softmax2(l.x, l.y, q0, q1);
+        }
+        const bool e = x_t[g] != 0;                               // posterior2 (gm_common.h) on the registers above
+        const float a0 = q0 * (e ? t1 : t0), b0 = q1 * (e ? t5 : t4), a1 = q0 * (e ? t3 : t2), b1 = q1 * (e ? t7 : t6);
+        p0 = a0 + b0;
+        p1 = a1 + b1;
+        const float uu = u ? u[base + v] : u01(o.v[k]);
+        const bool b = draw2(uu, p0, p1);
+        x_s[g] = b ? 1 : 0;
+        if (onehot) *reinterpret_cast<float2*>(onehot + 2 * g) = b ? make_float2(0.f, 1.f) : make_float2(1.f, 0.f);
+        if (post) *reinterpret_cast<float2*>(post + 2 * g) = make_float2(p0, p1);
+    }
 }
 
 // Wd[f][k] = W[2f+1][k] - W[2f][k], bd[f] = b[2f+1] - b[2f]: the last Linear of a node tower folded to one output per
@@ -127,7 +146,9 @@ static int attr_posterior_sample(int64_t n, int64_t F, const float* logits, cons
     GM_REQUIRE(aligned(logits, DIFF ? 4 : 8) && (!onehot_out || aligned(onehot_out, 8)) && (!post_dbg || aligned(post_dbg, 8)),
                "logits/onehot/post must be 8-byte aligned (a logit difference: 4-byte)");
     GM_REQUIRE(v_end - v_begin < (1ll << 31) && (F + 255) / 256 <= 65535, "grid too large");
-    hipLaunchKernelGGL(k_attr_posterior_sample<DIFF>, dim3((unsigned)(v_end - v_begin), (unsigned)((F + 255) / 256)), dim3(256), 0,
+    // groups of four nodes that can hold a node of the range for some shift s in 0..3: 4*q' - s + k in [v_begin, v_end)
+    const int64_t groups = ((v_end + 2) >> 2) - (v_begin >> 2) + 1;
+    hipLaunchKernelGGL(k_attr_posterior_sample<DIFF>, dim3((unsigned)groups, (unsigned)((F + 255) / 256)), dim3(256), 0,
                        as_stream(stream), n, F, logits, x_t, tab, u, seed, step, v_begin, v_end, x_s, onehot_out, post_dbg);
     GM_LAUNCH_CHECK();
     return GM_OK;

@@ -26,8 +26,14 @@ namespace gm {
 // is fetched across the L2 boundary about once instead of once per XCD.  With r < 8 slabs in a (last) round, XCD x takes slab
 // x % r and the rows are dealt over the XCDs that share a slab.  A wrong guess about placement costs speed only.
 constexpr int SP_SEG = 64;          // neighbours per segment (oracle: GMO_SPMM_SEG)
-constexpr int SP_RB = 32;           // rows per workgroup
-constexpr int SP_PARTS = 96;        // segment sums a workgroup can hold in LDS for its multi-segment rows (128-byte slabs)
+#ifndef GM_SPMM_RB                  // exploration builds (tools/spmm_ab.py) may override the two sizes below
+#define GM_SPMM_RB 32
+#endif
+#ifndef GM_SPMM_PARTS
+#define GM_SPMM_PARTS 96
+#endif
+constexpr int SP_RB = GM_SPMM_RB;   // rows per workgroup (<= 64: wave 0 lists them, a lane per row)
+constexpr int SP_PARTS = GM_SPMM_PARTS;        // segment sums a workgroup can hold in LDS for its multi-segment rows (128-byte slabs)
 constexpr int SP_PARTS_WIDE = 16;   // ... with 2 KB slabs (each sum is 16x larger)
 constexpr int SP_SERIAL = 0xFFFF;   // item that walks all segments of its row itself (LDS slots exhausted)
 
@@ -116,7 +122,17 @@ k_spmm_seg(int64_t n, const int32_t* __restrict__ rowptr, const int32_t* __restr
             if (tid >= off) { heavy_inc += t0; light_inc += t1; serial_inc += t2; }
         }
         const int heavy_total = __shfl(heavy_inc, 63), light_total = __shfl(light_inc, 63), serial_total = __shfl(serial_inc, 63);
-        const int item_base = serial ? serial_inc - 1 : fits ? serial_total + heavy_inc - ns : serial_total + heavy_total + light_inc - 1;
+        // single-segment rows are listed by descending degree: the 8 groups of a wave run in lockstep, so a round of items
+        // costs the wave its longest one, and neighbours in the list go to the same wave (a power-law graph mixes rows of
+        // 1 and 60 neighbours; unsorted, the SpMM of such a graph took 1.45x the time of a uniform graph with the same nnz)
+        const int key = (live && !multi) ? deg : -1;
+        int light_rank = 0;
+        for (int k = 0; k < SP_RB; ++k) {
+            const int dk = __shfl(key, k);
+            light_rank += (dk > key || (dk == key && k < r)) ? 1 : 0;
+        }
+        (void)light_inc;
+        const int item_base = serial ? serial_inc - 1 : fits ? serial_total + heavy_inc - ns : serial_total + heavy_total + light_rank;
         const int item_inc = serial_total + heavy_total + light_total;
         if (r < SP_RB) {
             row_b[r] = rb;
@@ -173,7 +189,10 @@ k_spmm_seg(int64_t n, const int32_t* __restrict__ rowptr, const int32_t* __restr
 #pragma unroll
                 for (int q = 0; q < NB; ++q) {
                     const bool in = k + q < cnt;
-                    const int j = in ? idx_s[g][k + q] : 0;
+                    int j = in ? idx_s[g][k + q] : 0;
+#ifdef GM_SPMM_X_SCRAMBLE   // exploration: same structure, gather targets spread uniformly (wrong results) -- isolates hot-row effects
+                    j = (int)(((uint32_t)j * 2654435761u) % (uint32_t)n);
+#endif
                     w[q] = TRANSPOSED ? (in ? w_s[g][k + q] : 0.0f) : inv_row;
 #pragma unroll
                     for (int c = 0; c < CH; ++c)
