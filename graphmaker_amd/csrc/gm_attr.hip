@@ -117,13 +117,17 @@ __global__ void k_prior_E_upper(int64_t n, int64_t wpr, float p0, float p1, cons
     const int64_t i = g / wpr, w = g % wpr;
     uint32_t word = 0;
     if (w >= (i >> 5)) {
-        for (int b = 0; b < 32; ++b) {
-            const int64_t j = w * 32 + b;
-            if (j >= i && j < n) {
-                const int64_t idx = i * n + j;
-                const float uu = u ? u[idx] : u_idx64(seed, 0u, STREAM_E_PRIOR, (uint64_t)idx);
-                if (draw2(uu, p0, p1)) word |= 1u << b;
+        const int64_t base = i * n + w * 32;                      // draw index of bit 0 of this word
+        if (u) {
+            for (int b = 0; b < 32; ++b) {
+                const int64_t j = w * 32 + b;
+                if (j >= i && j < n && draw2(u[base + b], p0, p1)) word |= 1u << b;
             }
+        } else {
+            u_idx64_run32(seed, 0u, STREAM_E_PRIOR, (uint64_t)base, [&](int b, float uu) {
+                const int64_t j = w * 32 + b;
+                if (j >= i && j < n && draw2(uu, p0, p1)) word |= 1u << b;
+            });
         }
     }
     upper[g] = word;

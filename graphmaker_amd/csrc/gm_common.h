@@ -77,6 +77,23 @@ __device__ __forceinline__ float u_idx64(uint64_t seed, uint32_t step, uint32_t 
     u32x4 o = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), step, stream, (uint32_t)seed, (uint32_t)(seed >> 32));
     return u01(pick4(o, (uint32_t)idx & 3u));
 }
+// fn(b, u) for the 32 consecutive draw indices base .. base+31 of one stream (b = 0..31): the same values as u_idx64, one
+// Philox block per four indices instead of one per index (9 blocks cover any alignment of base; control flow is uniform)
+template <class Fn>
+__device__ __forceinline__ void u_idx64_run32(uint64_t seed, uint32_t step, uint32_t stream, uint64_t base, Fn&& fn) {
+    const uint64_t q0 = base >> 2;
+    const int s = (int)(base & 3u);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const uint64_t q = q0 + (uint64_t)t;
+        const u32x4 o = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), step, stream, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int b = 4 * t + c - s;
+            if (b >= 0 && b < 32) fn(b, u01(o.v[c]));
+        }
+    }
+}
 __device__ __forceinline__ float u_pair(uint64_t seed, uint32_t step, uint32_t i, uint32_t j) {
     u32x4 o = philox4x32_10(j >> 2, i, step, STREAM_E, (uint32_t)seed, (uint32_t)(seed >> 32));
     return u01(pick4(o, j & 3u));

@@ -25,14 +25,18 @@ __global__ void k_noise_E_upper(int64_t n, int64_t wpr, const uint32_t* __restri
     uint32_t word = 0;
     if (w >= (i >> 5)) {
         const uint32_t w0 = bits0[g];
-        for (int b = 0; b < 32; ++b) {
+        const int64_t base = i * n + w * 32;                      // draw index of bit 0 of this word
+        auto one = [&](int b, float uu) {
             const int64_t j = w * 32 + b;
             if (j >= i && j < n) {
-                const int64_t idx = i * n + j;
-                const float uu = u ? u[idx] : u_idx64(seed, step, STREAM_E_NOISE, (uint64_t)idx);
-                const int e0 = (w0 >> b) & 1u;
-                if (draw2(uu, Q.q[2 * e0], Q.q[2 * e0 + 1])) word |= 1u << b;
+                const bool e0 = (w0 >> b) & 1u;
+                if (draw2(uu, e0 ? Q.q[2] : Q.q[0], e0 ? Q.q[3] : Q.q[1])) word |= 1u << b;
             }
+        };
+        if (u) {
+            for (int b = 0; b < 32; ++b) one(b, u[base + b < n * n ? base + b : 0]);
+        } else {
+            u_idx64_run32(seed, step, STREAM_E_NOISE, (uint64_t)base, one);
         }
     }
     upper[g] = word;
