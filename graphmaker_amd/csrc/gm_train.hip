@@ -190,16 +190,19 @@ static int launch_reduce(int S, int64_t M, int64_t N, const float* part, const f
                          int relu, float* C, int64_t ldc, hipStream_t s);
 
 // ---- column sums: part[blk][n] = sum over the block's rows (ascending, 4 row lanes combined in order)
-constexpr int CS_ROWS = 64;   // rows per block
+constexpr int CS_ROWS = 64;   // rows per block ...
+// ... up to 65536 rows; beyond (the pair batch: 2,097,152 rows) a block takes M/1024 rows, so that the second stage still
+// adds about a thousand partials per column, not 32768 in a handful of threads (db1 of the pair MLP: 0.29 + 0.80 ms)
+static inline int64_t colsum_rows(int64_t M) { return M <= 65536 ? CS_ROWS : ((M + 1023) / 1024 + 3) / 4 * 4; }
 __global__ void __launch_bounds__(256)
-k_colsum_partial(int64_t M, int64_t N, const float* __restrict__ X, int64_t ldx, float* __restrict__ part) {
+k_colsum_partial(int64_t M, int64_t N, const float* __restrict__ X, int64_t ldx, float* __restrict__ part, int64_t rows) {
     __shared__ float red[4][64];
     const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int64_t n = (int64_t)blockIdx.x * 64 + c;
-    const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS;
+    const int64_t r0 = (int64_t)blockIdx.y * rows;
     float acc = 0.0f;
     if (n < N)
-        for (int64_t m = r0 + rl; m < r0 + CS_ROWS && m < M; m += 4) acc = acc + X[m * ldx + n];
+        for (int64_t m = r0 + rl; m < r0 + rows && m < M; m += 4) acc = acc + X[m * ldx + n];
     red[rl][c] = acc;
     __syncthreads();
     if (rl == 0 && n < N) part[(int64_t)blockIdx.y * N + n] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
@@ -510,17 +513,21 @@ extern "C" int gm_gemm(int a_red, int b_red, int64_t M, int64_t N, int64_t K, co
     return GM_OK;
 }
 
-extern "C" int64_t gm_colsum_workspace_bytes(int64_t M, int64_t N) { return ((M + CS_ROWS - 1) / CS_ROWS) * N * 4; }
+extern "C" int64_t gm_colsum_workspace_bytes(int64_t M, int64_t N) {
+    const int64_t rows = colsum_rows(M);
+    return ((M + rows - 1) / rows) * N * 4;
+}
 
 extern "C" int gm_colsum(int64_t M, int64_t N, const float* X, int64_t ldx, float* out, void* workspace, int64_t workspace_bytes,
                          gm_stream_t stream) {
     GM_REQUIRE(M > 0 && N > 0 && X && out && ldx >= N, "bad arguments");
-    const int64_t nblk = (M + CS_ROWS - 1) / CS_ROWS;
+    const int64_t rows = colsum_rows(M);
+    const int64_t nblk = (M + rows - 1) / rows;
     GM_REQUIRE(workspace && workspace_bytes >= nblk * N * 4, "gm_colsum needs %lld workspace bytes", (long long)(nblk * N * 4));
     GM_REQUIRE(nblk < 65536, "M too large");
     hipStream_t s = as_stream(stream);
     float* part = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(k_colsum_partial, dim3((unsigned)((N + 63) / 64), (unsigned)nblk), dim3(256), 0, s, M, N, X, ldx, part);
+    hipLaunchKernelGGL(k_colsum_partial, dim3((unsigned)((N + 63) / 64), (unsigned)nblk), dim3(256), 0, s, M, N, X, ldx, part, rows);
     GM_LAUNCH_CHECK();
     return launch_reduce((int)nblk, 1, N, part, nullptr, nullptr, 0, 0, out, N, s);
 }

@@ -78,6 +78,10 @@ def test_colsum_and_relu_bwd(dev):
     g = torch.Generator().manual_seed(3)
     X = torch.randn(1000, 77, generator=g)
     _close(ag.colsum(X.to(dev)).cpu().numpy(), X.sum(0).numpy(), 1e-4, 1e-5, "colsum")
+    # more than 65536 rows (the pair batch): taller blocks, ragged last block, 2 and 130 columns
+    for M, N in ((70001, 2), (200003, 130)):
+        big = torch.randn(M, N, generator=g)
+        _close(ag.colsum(big.to(dev)).cpu().numpy(), big.double().sum(0).float().numpy(), 2e-3, 1e-4, f"colsum {M}x{N}")
     y = torch.randn(1000, 77, generator=g)
     out = torch.empty_like(X, device=dev)
     Xd, yd = X.to(dev), y.to(dev)
