@@ -212,9 +212,74 @@ k_linear(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t l
     }
 }
 
+// ---- a layer with at most 4 outputs over very many rows (the pair MLP's 128 -> 2 layer on a 2,097,152-pair training
+// batch): HBM-bound on reading A once, which a 128-wide MFMA tile does at 1.6 TB/s.  One lane per row keeps the
+// ascending-k fmaf chain of the header (same bits as k_linear); a wave stages 64 rows x 32 k through LDS so that global
+// reads stay 128-byte row pieces, W is read from LDS as a broadcast.
+constexpr int SK_KC = 32, SK_LD = SK_KC + 4, SK_MAXK = 1024;
+template <int NOUT>
+__global__ void __launch_bounds__(256)
+k_linear_skinny(int64_t M, int64_t K, const float* __restrict__ A, int64_t lda, const float* __restrict__ W, int64_t ldw,
+                const float* __restrict__ bias, float* __restrict__ C, int64_t ldc, int relu) {
+    __shared__ __attribute__((aligned(16))) float tile[4][64 * SK_LD];
+    __shared__ __attribute__((aligned(16))) float Ws[NOUT * SK_MAXK];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    for (int e = tid; e < NOUT * (int)K; e += 256) Ws[e] = W[(int64_t)(e / (int)K) * ldw + e % (int)K];
+    __syncthreads();
+    const int64_t r0 = ((int64_t)blockIdx.x * 4 + wv) * 64;
+    if (r0 >= M) return;
+    float* t = tile[wv];
+    float acc[NOUT];
+#pragma unroll
+    for (int c = 0; c < NOUT; ++c) acc[c] = 0.0f;
+    const int lr = lane >> 3, lq = lane & 7;                    // staging: 8 rows x 8 float4 per pass
+    for (int kc = 0; kc < (int)K; kc += SK_KC) {
+        float4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t m = r0 + lr + 8 * i;
+            v[i] = m < M ? *reinterpret_cast<const float4*>(A + m * lda + kc + 4 * lq) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(t + (lr + 8 * i) * SK_LD + 4 * lq) = v[i];
+        // a wave's LDS writes and reads are served in order: no barrier needed between the passes of one wave
+#pragma unroll
+        for (int q = 0; q < SK_KC / 4; ++q) {
+            const float4 a = *reinterpret_cast<const float4*>(t + lane * SK_LD + 4 * q);
+#pragma unroll
+            for (int c = 0; c < NOUT; ++c) {
+                const float4 w = *reinterpret_cast<const float4*>(Ws + c * (int)K + kc + 4 * q);
+                acc[c] = __builtin_fmaf(a.x, w.x, acc[c]);
+                acc[c] = __builtin_fmaf(a.y, w.y, acc[c]);
+                acc[c] = __builtin_fmaf(a.z, w.z, acc[c]);
+                acc[c] = __builtin_fmaf(a.w, w.w, acc[c]);
+            }
+        }
+    }
+    const int64_t m = r0 + lane;
+    if (m < M) {
+#pragma unroll
+        for (int c = 0; c < NOUT; ++c) {
+            float v = acc[c];
+            if (bias) v = v + bias[c];
+            if (relu && !(v > 0.0f)) v = 0.0f;
+            C[m * ldc + c] = v;
+        }
+    }
+}
+
 }  // namespace gm
 
 using namespace gm;
+
+template <int NOUT>
+static int launch_skinny(int64_t M, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+                         float* C, int64_t ldc, int relu, hipStream_t s) {
+    hipLaunchKernelGGL((k_linear_skinny<NOUT>), dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, M, K, A, lda, W, ldw, bias, C,
+                       ldc, relu);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
+}
 
 template <int TM, int TN, int KT, int OCC, int WGM = 2, int WGN = 2>
 static int launch_linear(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw,
@@ -248,6 +313,14 @@ extern "C" int gm_linear(int64_t M, int64_t N, int64_t K, const float* A, int64_
 #ifdef GM_GEMM_CFG   // exploration builds (tools/build_gemm_variant.sh): one configuration for every shape
     return launch_linear<GM_GEMM_CFG>(M, N, K, A, lda, W, ldw, bias, C, ldc, relu, s);
 #endif
+    if (N <= 4 && M >= 65536 && K % SK_KC == 0 && K <= SK_MAXK && lda % 4 == 0 && aligned(A, 16) && (M + 255) / 256 < (1ll << 31)) {
+        switch ((int)N) {      // the pair MLP's output layer on a training batch: see k_linear_skinny
+            case 1: return launch_skinny<1>(M, K, A, lda, W, ldw, bias, C, ldc, relu, s);
+            case 2: return launch_skinny<2>(M, K, A, lda, W, ldw, bias, C, ldc, relu, s);
+            case 3: return launch_skinny<3>(M, K, A, lda, W, ldw, bias, C, ldc, relu, s);
+            default: return launch_skinny<4>(M, K, A, lda, W, ldw, bias, C, ldc, relu, s);
+        }
+    }
     const int64_t tiles128 = ((N + 127) / 128) * ((M + 127) / 128);
     // wide layers with many rows: 128x256 block tile, 4x4 waves of 32x64 (a third of the operand traffic per FLOP of the 64x64 tile);
     // everything else: 64x64 block tile, 2x2 waves of 32x32, four workgroups per CU

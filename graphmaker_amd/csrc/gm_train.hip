@@ -154,6 +154,51 @@ k_gemm_g(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t l
     }
 }
 
+// ---- C[m][n] = sum_k A[k][m] B[k][n] with at most 4 rows m, at most 128 columns n and a very long k (dW2 of the pair MLP:
+// 2 x 128 over the 2,097,152 pairs of a training batch).  HBM-bound on reading B once; a 128x128 MFMA tile spends its time
+// on 126 rows of padding.  A block owns a k range; thread (n, row lane) walks it in ascending k (stride 2, four loads in
+// flight), the two lanes are combined in order, and the per-block sums go through the split-K reduction above in
+// ascending block order (fixed order, like every other sum here).
+template <int MR>
+__global__ void __launch_bounds__(256)
+k_gemm_tt_skinny(int64_t N, int64_t K, const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
+                 float* __restrict__ part, int64_t kchunk, int64_t split_stride) {
+    __shared__ float red[MR][128];
+    const int n = threadIdx.x & 127, rl = threadIdx.x >> 7;
+    const int64_t kb = (int64_t)blockIdx.x * kchunk, ke = kb + kchunk < K ? kb + kchunk : K;
+    float acc[MR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) acc[m] = 0.0f;
+    if (n < N) {
+        int64_t k = kb + rl;
+        for (; k + 6 < ke; k += 8) {
+            float b[4], a[4][MR];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                b[q] = B[(k + 2 * q) * ldb + n];
+#pragma unroll
+                for (int m = 0; m < MR; ++m) a[q][m] = A[(k + 2 * q) * lda + m];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int m = 0; m < MR; ++m) acc[m] = __builtin_fmaf(a[q][m], b[q], acc[m]);
+        }
+        for (; k < ke; k += 2) {
+            const float b = B[k * ldb + n];
+#pragma unroll
+            for (int m = 0; m < MR; ++m) acc[m] = __builtin_fmaf(A[k * lda + m], b, acc[m]);
+        }
+    }
+    if (rl == 1)
+#pragma unroll
+        for (int m = 0; m < MR; ++m) red[m][n] = acc[m];
+    __syncthreads();
+    if (rl == 0 && n < N)
+#pragma unroll
+        for (int m = 0; m < MR; ++m) part[(int64_t)blockIdx.x * split_stride + m * N + n] = acc[m] + red[m][n];
+}
+
 // C[m][n] = finish( sum_{s ascending} part[s][m][n] )
 __global__ void k_splitk_reduce(int S, int64_t M, int64_t N, const float* __restrict__ part, const float* __restrict__ bias,
                                 const float* __restrict__ mask, int64_t ldmask, int relu, float* __restrict__ C, int64_t ldc) {
@@ -459,7 +504,12 @@ static int launch_reduce(int S, int64_t M, int64_t N, const float* part, const f
     return GM_OK;
 }
 
+static inline bool tt_skinny(int a_red, int b_red, int64_t M, int64_t N, int64_t K) {
+    return a_red && b_red && M <= 4 && N <= 128 && K >= 65536;
+}
 static inline int pick_splits(int64_t M, int64_t N, int64_t K) {
+    if (M <= 4 && N <= 128 && K >= 65536) return 2048;      // k_gemm_tt_skinny: one block per k range (also covers the
+                                                            // workspace of the general kernel, which asks for fewer)
     const int64_t tiles = ((M + TBM - 1) / TBM) * ((N + TBN - 1) / TBN);
     int64_t s = 512 / tiles;
     const int64_t kmax = K / 256;
@@ -486,6 +536,23 @@ extern "C" int gm_gemm(int a_red, int b_red, int64_t M, int64_t N, int64_t K, co
     hipStream_t s = as_stream(stream);
     int splits = pick_splits(M, N, K);
     int64_t kchunk = K;
+    if (tt_skinny(a_red, b_red, M, N, K)) {
+        kchunk = ((K + splits - 1) / splits + 1) / 2 * 2;      // even: the two row lanes of a block keep their parity
+        splits = (int)((K + kchunk - 1) / kchunk);
+        GM_REQUIRE(workspace && workspace_bytes >= (int64_t)splits * M * N * 4, "gm_gemm needs %lld workspace bytes (gm_gemm_workspace_bytes)",
+                   (long long)((int64_t)splits * M * N * 4));
+        float* part = static_cast<float*>(workspace);
+#define GM_LAUNCH_SK(MR) hipLaunchKernelGGL((k_gemm_tt_skinny<MR>), dim3((unsigned)splits), dim3(256), 0, s, N, K, A, lda, B, ldb, part, kchunk, M * N)
+        switch ((int)M) {
+            case 1: GM_LAUNCH_SK(1); break;
+            case 2: GM_LAUNCH_SK(2); break;
+            case 3: GM_LAUNCH_SK(3); break;
+            default: GM_LAUNCH_SK(4); break;
+        }
+#undef GM_LAUNCH_SK
+        GM_LAUNCH_CHECK();
+        return launch_reduce(splits, M, N, part, bias, mask, ldmask, relu, C, ldc, s);
+    }
     if (splits > 1) {
         kchunk = ((K + splits - 1) / splits + TBK - 1) / TBK * TBK;
         splits = (int)((K + kchunk - 1) / kchunk);

@@ -215,7 +215,11 @@ def test_spmm_mean_skewed_degrees_and_hub_rows(dev, n, d, mean_deg, max_deg):
                                              (3000, 2310, 70, True, True), (2700, 2400, 37, False, False),
                                              # the same configuration with a K long enough for its steady-state loop
                                              # (two register sets, step_fast) and a ragged last k-tile: the mlp_out shape
-                                             (3000, 2310, 1744, True, True), (2600, 2500, 1101, False, True)])
+                                             (3000, 2310, 1744, True, True), (2600, 2500, 1101, False, True),
+                                             # at most 4 outputs over >= 65536 rows (the pair MLP's output layer on a training
+                                             # batch): k_linear_skinny, ragged last wave; K not a multiple of 32 stays on k_linear
+                                             (70001, 2, 128, False, True), (65536, 4, 64, True, True), (65600, 1, 32, False, False),
+                                             (65700, 3, 100, False, True)])
 def test_linear(dev, M, N, K, relu, bias):
     ops = _ops()
     rs = np.random.RandomState(M + N + K)

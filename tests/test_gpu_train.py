@@ -72,6 +72,25 @@ def test_gemm_variants(dev, M, N, K):
     _close(o.cpu().numpy(), ref2, 2e-5 * scale, 1e-5, "gemm epilogue")
 
 
+@pytest.mark.parametrize("M,N,K", [(2, 128, 70001), (4, 100, 65539), (1, 7, 131072), (3, 128, 65536)])
+def test_gemm_skinny_weight_gradient(dev, M, N, K):
+    """dW of a layer with <= 4 outputs over a pair batch (k_gemm_tt_skinny): C = A^T B with a very long reduced dimension,
+    plus the epilogue, against float64."""
+    ag = _ag()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(K, M, generator=g)
+    B = torch.randn(K, N, generator=g)
+    ref = (A.double().T @ B.double())
+    tol = 3e-6 * float(K) ** 0.5 * 4
+    out = ag.gemm(True, True, M, N, K, A.to(dev), M, B.to(dev), N)
+    _close(out.cpu().numpy(), ref.numpy(), tol, 1e-5, f"skinny dW {M}x{N}x{K}")
+    again = ag.gemm(True, True, M, N, K, A.to(dev), M, B.to(dev), N)
+    assert torch.equal(out, again)                                  # fixed summation order
+    b = torch.randn(N, generator=g)
+    o = ag.gemm(True, True, M, N, K, A.to(dev), M, B.to(dev), N, bias=b.to(dev), relu=True)
+    _close(o.cpu().numpy(), torch.relu(ref + b.double()).numpy(), tol, 1e-5, "skinny dW epilogue")
+
+
 def test_colsum_and_relu_bwd(dev):
     ag = _ag()
     from graphmaker_amd import _lib as L
