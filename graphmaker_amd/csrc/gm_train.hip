@@ -511,11 +511,23 @@ static inline int pick_splits(int64_t M, int64_t N, int64_t K) {
     if (M <= 4 && N <= 128 && K >= 65536) return 2048;      // k_gemm_tt_skinny: one block per k range (also covers the
                                                             // workspace of the general kernel, which asks for fewer)
     const int64_t tiles = ((M + TBM - 1) / TBM) * ((N + TBN - 1) / TBN);
-    int64_t s = 512 / tiles;
-    const int64_t kmax = K / 256;
-    if (s > kmax) s = kmax;
-    if (s > 1024) s = 1024;
-    return s < 2 ? 1 : (int)s;
+    int64_t smax = K / 256;
+    if (smax > 1024) smax = 1024;
+    if (tiles >= 512 || smax < 2) return 1;
+    // the grid is tiles x splits workgroups on 512 slots (256 CUs, two workgroups each): take the split count that fills
+    // whole rounds best, each further split charged for its share of the reduction pass.  1744 x 1744 over 13752 rows is 196
+    // tiles: 2 splits (392 workgroups, 0.77 of a round) took 1.04 ms, 5 splits (980 = 0.96 of two rounds) take less.
+    const double charge = 0.01 * (tiles < 196 ? (double)tiles / 196.0 : 1.0);
+    int64_t best = 1;
+    double best_score = -1.0;
+    const int64_t stop = smax < 2 * (512 / tiles + 1) ? smax : 2 * (512 / tiles + 1);
+    for (int64_t c = 1; c <= stop; ++c) {
+        const int64_t w = tiles * c;
+        const double fill = (double)w / (double)(((w + 511) / 512) * 512);
+        const double score = fill - charge * (double)c;
+        if (score > best_score) { best_score = score; best = c; }
+    }
+    return (int)best;
 }
 
 }  // namespace gm
