@@ -378,15 +378,39 @@ k_hadamard_gather_bwd(int64_t n, int64_t B, int d, const int64_t* __restrict__ s
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
     const int64_t b0 = segptr[i], b1 = segptr[i + 1];
+    // A node of the pair batch has some 300 entries; walked one at a time, each is a chain of three dependent loads (order ->
+    // src/dst -> the two rows) and the wave waits for every link (1.27 ms at 2M pairs).  The lanes resolve 64 entries at once,
+    // then the rows of 8 entries are in flight together; the fmaf chain itself stays in ascending k.
     for (int c0 = 0; c0 < d; c0 += 128) {
         float acc0 = 0.0f, acc1 = 0.0f;
         const int ca = c0 + lane, cb = c0 + 64 + lane;
-        for (int64_t k = b0; k < b1; ++k) {
-            const int64_t it = order[k];
-            const int64_t b = it >= B ? it - B : it;
-            const int64_t other = it >= B ? src[b] : dst[b];
-            if (ca < d) acc0 = __builtin_fmaf(dZ[b * lddz + ca], h[other * ldh + ca], acc0);
-            if (cb < d) acc1 = __builtin_fmaf(dZ[b * lddz + cb], h[other * ldh + cb], acc1);
+        for (int64_t k0 = b0; k0 < b1; k0 += 64) {
+            const int cnt = b1 - k0 < 64 ? (int)(b1 - k0) : 64;
+            int my_b = 0, my_o = 0;
+            if (lane < cnt) {
+                const int64_t it = order[k0 + lane];
+                const int64_t b = it >= B ? it - B : it;
+                my_b = (int)b;
+                my_o = (int)(it >= B ? src[b] : dst[b]);
+            }
+            for (int q0 = 0; q0 < cnt; q0 += 8) {
+                float z0[8], z1[8], g0[8], g1[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const bool in = q0 + q < cnt;
+                    const int64_t b = __shfl(my_b, (q0 + q) & 63), o = __shfl(my_o, (q0 + q) & 63);
+                    z0[q] = in && ca < d ? dZ[b * lddz + ca] : 0.0f;
+                    g0[q] = in && ca < d ? h[o * ldh + ca] : 0.0f;
+                    z1[q] = in && cb < d ? dZ[b * lddz + cb] : 0.0f;
+                    g1[q] = in && cb < d ? h[o * ldh + cb] : 0.0f;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (q0 + q < cnt) {
+                        acc0 = __builtin_fmaf(z0[q], g0[q], acc0);
+                        acc1 = __builtin_fmaf(z1[q], g1[q], acc1);
+                    }
+            }
         }
         if (ca < d) dh[i * lddh + ca] = acc0;
         if (cb < d) dh[i * lddh + cb] = acc1;
@@ -665,6 +689,7 @@ extern "C" int gm_hadamard_gather_bwd(int64_t n, int64_t B, int64_t d, const int
                                       int64_t lddz, float* dh, int64_t lddh, gm_stream_t stream) {
     GM_REQUIRE(n > 0 && B > 0 && d > 0 && src && dst && segptr && order && h && dZ && dh, "bad arguments");
     GM_REQUIRE(ldh >= d && lddz >= d && lddh >= d, "leading dimension too small");
+    GM_REQUIRE(B < (1ll << 31) && n < (1ll << 31), "batch or node count too large");
     hipLaunchKernelGGL(k_hadamard_gather_bwd, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, as_stream(stream), n, B, (int)d, src,
                        dst, segptr, order, h, ldh, dZ, lddz, dh, lddh);
     GM_LAUNCH_CHECK();

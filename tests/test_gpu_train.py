@@ -193,17 +193,21 @@ def test_embedding_hadamard_ce_backward(dev):
     assert torch.equal(o.detach().cpu(), Wt[idx])
     _close(Wd.grad.cpu().numpy(), Wc.grad.numpy(), 1e-5, 1e-5, "embedding backward")
 
-    h = torch.randn(n, d, generator=g)
-    src = torch.randint(0, n, (B,), generator=g)
-    dst = torch.randint(0, n, (B,), generator=g)
-    gz = torch.randn(B, d, generator=g)
-    hc = h.clone().requires_grad_(True)
-    (hc[src] * hc[dst]).backward(gz)
-    hd = h.to(dev).requires_grad_(True)
-    z = ag.hadamard_gather(hd, src.to(dev), dst.to(dev))
-    z.backward(gz.to(dev))
-    assert torch.equal(z.detach().cpu(), h[src] * h[dst])
-    _close(hd.grad.cpu().numpy(), hc.grad.numpy(), 2e-5, 1e-5, "hadamard backward")
+    # widths on the float4 path (d/4 a power of two) and off it; nodes with far more than 64 batch entries (the backward
+    # resolves 64 entries at a time) and nodes with none
+    for n_h, d_h, B_h in ((n, d, B), (5, 128, 700), (40, 200, 333), (7, 20, 100), (3, 64, 1000), (300, 256, 50)):
+        h = torch.randn(n_h, d_h, generator=g)
+        src = torch.randint(0, n_h, (B_h,), generator=g)
+        dst = torch.randint(0, n_h, (B_h,), generator=g)
+        gz = torch.randn(B_h, d_h, generator=g)
+        hc = h.clone().requires_grad_(True)
+        (hc[src] * hc[dst]).backward(gz)
+        hd = h.to(dev).requires_grad_(True)
+        z = ag.hadamard_gather(hd, src.to(dev), dst.to(dev))
+        z.backward(gz.to(dev))
+        assert torch.equal(z.detach().cpu(), h[src] * h[dst])
+        scale = max(1.0, float(hc.grad.abs().max()))
+        _close(hd.grad.cpu().numpy(), hc.grad.numpy(), 2e-5 * scale, 1e-5, f"hadamard backward n={n_h} d={d_h} B={B_h}")
 
     logits = torch.randn(5000, 2, generator=g) * 3
     tgt = torch.randint(0, 2, (5000,), generator=g)
