@@ -261,7 +261,9 @@ class _HadamardGather(torch.autograd.Function):
         B = src.numel()
         # group the 2B (pair, role) entries by node: index plumbing (a stable sort of the ids), then one kernel
         keys = torch.cat([src, dst])
-        order = torch.argsort(keys, stable=True)
+        # node ids fit 16 (or 32) bits: the radix sort then makes 2 (4) passes over the 2B keys instead of 8
+        narrow = keys.to(torch.int16) if n <= 32767 else keys.to(torch.int32) if n <= 2**31 - 1 else keys
+        order = torch.argsort(narrow, stable=True)
         counts = torch.bincount(keys, minlength=n)
         segptr = torch.zeros(n + 1, dtype=torch.int64, device=h.device)
         segptr[1:] = torch.cumsum(counts, 0)
