@@ -19,7 +19,7 @@ EXPORTS = [
     "gm_tower_forward", "gm_tower_stage", "gm_tower_prep_floats", "gm_tower_prepare", "gm_onehot_prep_floats", "gm_onehot_prepare", "gm_onehot_linear", "gm_hadamard_gather", "gm_pair_score_sample", "gm_pair_score_sample_ranges", "gm_pair_score_sample_bf16", "gm_attr_posterior_sample", "gm_attr_posterior_sample_diff", "gm_head_diff_prepare", "gm_onehot_from_x",
     "gm_x_from_onehot", "gm_prior_Y", "gm_prior_X", "gm_prior_E", "gm_prior_E_static",
     "gm_noise_E", "gm_noise_X", "gm_bitmap_from_onehot_f32", "gm_x_from_onehot3d",
-    "gm_gemm_workspace_bytes", "gm_gemm", "gm_colsum_workspace_bytes", "gm_colsum", "gm_layernorm_fwd",
+    "gm_gemm_workspace_bytes", "gm_gemm", "gm_mlp2_hidden_grad_workspace_bytes", "gm_mlp2_hidden_grad", "gm_colsum_workspace_bytes", "gm_colsum", "gm_layernorm_fwd",
     "gm_layernorm_bwd_workspace_bytes", "gm_layernorm_bwd", "gm_spmm_mean_bwd", "gm_embedding_bwd_workspace_bytes", "gm_embedding_bwd",
     "gm_hadamard_gather_bwd", "gm_softmax_ce2_workspace_bytes", "gm_softmax_ce2",
     "gm_relu_bwd", "gm_dropout", "gm_embedding_fwd", "gm_denoise_match2", "gm_bitmap_lookup",
@@ -54,7 +54,7 @@ def load():
         lib = C.CDLL(LIB_PATH)
         lib.gm_last_error.restype = C.c_char_p
         lib.gm_version.restype = C.c_int
-        for name in ("gm_tower_prep_floats", "gm_onehot_prep_floats", "gm_gemm_workspace_bytes", "gm_colsum_workspace_bytes", "gm_layernorm_bwd_workspace_bytes",
+        for name in ("gm_tower_prep_floats", "gm_onehot_prep_floats", "gm_gemm_workspace_bytes", "gm_mlp2_hidden_grad_workspace_bytes", "gm_colsum_workspace_bytes", "gm_layernorm_bwd_workspace_bytes",
                      "gm_softmax_ce2_workspace_bytes", "gm_embedding_bwd_workspace_bytes"):
             getattr(lib, name).restype = C.c_int64
         _lib = lib

@@ -147,8 +147,18 @@ class _Mlp2(torch.autograd.Function):
         need = ctx.needs_input_grad
         dW2 = gemm(True, True, N, H, M, g, N, y1, H) if need[3] else None
         db2 = colsum(g) if ctx.has_bias[1] and need[4] else None
-        g1 = gemm(False, True, M, H, N, g, N, W2, H, mask=y1)          # (dY W2) where the hidden unit was active
-        dx, dW1, db1 = _linear_backward(x, W1, g1, (need[0], need[1], ctx.has_bias[0] and need[2]))
+        want_db1 = ctx.has_bias[0] and need[2]
+        ws_bytes = L.load().gm_mlp2_hidden_grad_workspace_bytes(I64(M), I64(H), I64(N))
+        if ws_bytes >= 0:      # few outputs (the pair MLP): hidden gradient and its column sums in one pass over the batch
+            g1 = torch.empty((M, H), dtype=torch.float32, device=g.device)
+            db1 = torch.empty(H, dtype=torch.float32, device=g.device) if want_db1 else None
+            ws = _scratch(ws_bytes, g.device) if want_db1 else None
+            L.call("gm_mlp2_hidden_grad", I64(M), I64(H), I64(N), ptr(g), ptr(W2), I64(H), ptr(y1), ptr(g1), ptr(db1), ptr(ws),
+                   I64(ws.numel() if ws is not None else 0), stream_ptr())
+            dx, dW1, _ = _linear_backward(x, W1, g1, (need[0], need[1], False))
+        else:
+            g1 = gemm(False, True, M, H, N, g, N, W2, H, mask=y1)          # (dY W2) where the hidden unit was active
+            dx, dW1, db1 = _linear_backward(x, W1, g1, (need[0], need[1], want_db1))
         return dx, dW1, db1, dW2, db2, None, None
 
 

@@ -253,6 +253,55 @@ k_colsum_partial(int64_t M, int64_t N, const float* __restrict__ X, int64_t ldx,
     if (rl == 0 && n < N) part[(int64_t)blockIdx.y * N + n] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
 }
 
+// ---- hidden gradient of Linear -> ReLU -> Linear when the second layer has at most 4 outputs (the pair MLP: 128 -> 2):
+//      g1[m][k] = y1[m][k] > 0 ? sum_c g[m][c] W2[c][k] : 0   (fmaf chain over c from 0: the bits gm_gemm(0,1) + mask gives)
+//      db1[k]   = sum_m g1[m][k]
+// one pass over y1 and g1 (1 GB each at 2M pairs) instead of a 128x128 MFMA tile on a K = 2 product (0.83 ms) followed by a
+// column-sum pass that reads g1 again (0.28 ms).  Thread = (float4 column group, row lane); a block owns `rows` rows; column
+// sums: ascending rows per lane, lanes in order, blocks in order (k_splitk_reduce).
+template <int NC>
+__global__ void __launch_bounds__(256)
+k_mlp2_hidden_grad(int64_t M, int H4, int shift, const float* __restrict__ g, const float* __restrict__ W2, int64_t ldw,
+                   const float* __restrict__ y1, float* __restrict__ g1, float* __restrict__ part, int64_t rows) {
+    __shared__ float4 red[256];
+    const int c4 = threadIdx.x & (H4 - 1), rl = threadIdx.x >> shift, nrl = 256 >> shift;
+    float4 w[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) w[c] = *reinterpret_cast<const float4*>(W2 + c * ldw + 4 * c4);
+    const int64_t r0 = (int64_t)blockIdx.x * rows, r1 = r0 + rows < M ? r0 + rows : M;
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t m = r0 + rl; m < r1; m += nrl) {
+        const float4 y = *reinterpret_cast<const float4*>(y1 + (m * H4 + c4) * 4);
+        float gm_[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) gm_[c] = g[m * NC + c];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            v.x = __builtin_fmaf(gm_[c], w[c].x, v.x);
+            v.y = __builtin_fmaf(gm_[c], w[c].y, v.y);
+            v.z = __builtin_fmaf(gm_[c], w[c].z, v.z);
+            v.w = __builtin_fmaf(gm_[c], w[c].w, v.w);
+        }
+        if (!(y.x > 0.0f)) v.x = 0.0f;
+        if (!(y.y > 0.0f)) v.y = 0.0f;
+        if (!(y.z > 0.0f)) v.z = 0.0f;
+        if (!(y.w > 0.0f)) v.w = 0.0f;
+        *reinterpret_cast<float4*>(g1 + (m * H4 + c4) * 4) = v;
+        sum.x = sum.x + v.x; sum.y = sum.y + v.y; sum.z = sum.z + v.z; sum.w = sum.w + v.w;
+    }
+    red[threadIdx.x] = sum;
+    __syncthreads();
+    if (rl == 0 && part) {
+        float4 t = red[c4];
+        for (int l = 1; l < nrl; ++l) {
+            const float4 a = red[(l << shift) + c4];
+            t.x = t.x + a.x; t.y = t.y + a.y; t.z = t.z + a.z; t.w = t.w + a.w;
+        }
+        *reinterpret_cast<float4*>(part + ((int64_t)blockIdx.x * H4 + c4) * 4) = t;
+    }
+}
+
 // ---- LayerNorm forward with saved statistics (same arithmetic as k_layernorm in gm_nodeops.hip)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -633,6 +682,44 @@ extern "C" int gm_colsum(int64_t M, int64_t N, const float* X, int64_t ldx, floa
     hipLaunchKernelGGL(k_colsum_partial, dim3((unsigned)((N + 63) / 64), (unsigned)nblk), dim3(256), 0, s, M, N, X, ldx, part, rows);
     GM_LAUNCH_CHECK();
     return launch_reduce((int)nblk, 1, N, part, nullptr, nullptr, 0, 0, out, N, s);
+}
+
+static inline bool hidden_grad_ok(int64_t H, int64_t N) {
+    const int64_t h4 = H / 4;
+    return H % 4 == 0 && h4 >= 1 && h4 <= 256 && (h4 & (h4 - 1)) == 0 && N >= 1 && N <= 4;
+}
+extern "C" int64_t gm_mlp2_hidden_grad_workspace_bytes(int64_t M, int64_t H, int64_t N) {
+    if (!hidden_grad_ok(H, N) || M <= 0) return -1;
+    const int64_t rows = colsum_rows(M);
+    return ((M + rows - 1) / rows) * H * 4;
+}
+
+extern "C" int gm_mlp2_hidden_grad(int64_t M, int64_t H, int64_t N, const float* g, const float* W2, int64_t ldw, const float* y1,
+                                   float* g1, float* db1, void* workspace, int64_t workspace_bytes, gm_stream_t stream) {
+    GM_REQUIRE(M > 0 && g && W2 && y1 && g1 && ldw >= H, "bad arguments");
+    GM_REQUIRE(hidden_grad_ok(H, N), "hidden width %lld must be 4 x a power of two up to 1024 and the output width %lld at most 4",
+               (long long)H, (long long)N);
+    GM_REQUIRE(ldw % 4 == 0 && aligned(W2, 16) && aligned(y1, 16) && aligned(g1, 16), "W2, y1, g1 must be 16-byte aligned");
+    const int64_t rows = colsum_rows(M), nblk = (M + rows - 1) / rows;
+    GM_REQUIRE(!db1 || (workspace && workspace_bytes >= nblk * H * 4 && aligned(workspace, 16)),
+               "gm_mlp2_hidden_grad needs %lld workspace bytes", (long long)(nblk * H * 4));
+    GM_REQUIRE(nblk < (1ll << 31), "M too large");
+    hipStream_t s = as_stream(stream);
+    const int H4 = (int)(H / 4);
+    int shift = 0;
+    while ((1 << shift) < H4) ++shift;
+    float* part = db1 ? static_cast<float*>(workspace) : nullptr;
+#define GM_LAUNCH_HG(NC) hipLaunchKernelGGL((k_mlp2_hidden_grad<NC>), dim3((unsigned)nblk), dim3(256), 0, s, M, H4, shift, g, W2, ldw, y1, g1, part, rows)
+    switch ((int)N) {
+        case 1: GM_LAUNCH_HG(1); break;
+        case 2: GM_LAUNCH_HG(2); break;
+        case 3: GM_LAUNCH_HG(3); break;
+        default: GM_LAUNCH_HG(4); break;
+    }
+#undef GM_LAUNCH_HG
+    GM_LAUNCH_CHECK();
+    if (db1) return launch_reduce((int)nblk, 1, H, part, nullptr, nullptr, 0, 0, db1, H, s);
+    return GM_OK;
 }
 
 extern "C" int gm_layernorm_fwd(int64_t M, int64_t N, const float* X, int64_t ldx, const float* gamma, const float* beta,

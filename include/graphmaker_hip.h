@@ -263,6 +263,13 @@ int64_t gm_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int gm_gemm(int a_red, int b_red, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
             int64_t ldb, const float* bias, const float* mask, int64_t ldmask, int relu, float* C, int64_t ldc,
             void* workspace, int64_t workspace_bytes, gm_stream_t stream);
+/* Hidden gradient of Linear -> ReLU -> Linear (model/gnn.py:227-231, the pair MLP) when the second layer has N <= 4 outputs:
+ * g1[m][k] = y1[m][k] > 0 ? sum_c g[m][c] W2[c][k] : 0 (the bits of gm_gemm(0,1,...) with mask = y1) and, if db1 is given,
+ * db1[k] = sum_m g1[m][k], in one pass over the M x H arrays.  g (M,N) and y1, g1 (M,H) are dense row-major; H = 4 x a power
+ * of two up to 1024.  The workspace (only needed for db1) is gm_mlp2_hidden_grad_workspace_bytes (-1: shape not supported). */
+int64_t gm_mlp2_hidden_grad_workspace_bytes(int64_t M, int64_t H, int64_t N);
+int gm_mlp2_hidden_grad(int64_t M, int64_t H, int64_t N, const float* g, const float* W2, int64_t ldw, const float* y1, float* g1,
+                        float* db1, void* workspace, int64_t workspace_bytes, gm_stream_t stream);
 /* out[n] = sum_m X[m][n]  (bias gradient) */
 int64_t gm_colsum_workspace_bytes(int64_t M, int64_t N);
 int gm_colsum(int64_t M, int64_t N, const float* X, int64_t ldx, float* out, void* workspace, int64_t workspace_bytes,

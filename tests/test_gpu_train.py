@@ -91,6 +91,35 @@ def test_gemm_skinny_weight_gradient(dev, M, N, K):
     _close(o.cpu().numpy(), torch.relu(ref + b.double()).numpy(), tol, 1e-5, "skinny dW epilogue")
 
 
+@pytest.mark.parametrize("M,H,N", [(1000, 128, 2), (70001, 128, 2), (333, 64, 4), (65, 4, 1), (130, 1024, 3)])
+def test_mlp2_hidden_grad_fused(dev, M, H, N):
+    """gm_mlp2_hidden_grad: the masked hidden gradient equals gm_gemm(0,1) + mask bit for bit, its column sums equal the
+    float64 sums within rounding; unsupported shapes report -1."""
+    ag = _ag()
+    from graphmaker_amd import _lib as L
+    g = torch.Generator().manual_seed(M + H + N)
+    gy = torch.randn(M, N, generator=g).to(dev)
+    W2 = torch.randn(N, H, generator=g).to(dev)
+    y1 = torch.relu(torch.randn(M, H, generator=g)).to(dev)
+    want = ag.gemm(False, True, M, H, N, gy, N, W2, H, mask=y1)
+    nbytes = L.load().gm_mlp2_hidden_grad_workspace_bytes(L.I64(M), L.I64(H), L.I64(N))
+    assert nbytes > 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    g1 = torch.empty(M, H, device=dev)
+    db1 = torch.empty(H, device=dev)
+    L.call("gm_mlp2_hidden_grad", L.I64(M), L.I64(H), L.I64(N), L.ptr(gy), L.ptr(W2), L.I64(H), L.ptr(y1), L.ptr(g1), L.ptr(db1),
+           L.ptr(ws), L.I64(nbytes), L.stream_ptr())
+    assert torch.equal(g1, want)
+    ref = want.double().sum(0).cpu().numpy()
+    _close(db1.cpu().numpy(), ref, 1e-5 * float(M) ** 0.5 * 4, 1e-5, "db1")
+    g1b = torch.empty(M, H, device=dev)                                     # without the bias gradient: no workspace
+    L.call("gm_mlp2_hidden_grad", L.I64(M), L.I64(H), L.I64(N), L.ptr(gy), L.ptr(W2), L.I64(H), L.ptr(y1), L.ptr(g1b), None, None,
+           L.I64(0), L.stream_ptr())
+    assert torch.equal(g1b, want)
+    assert L.load().gm_mlp2_hidden_grad_workspace_bytes(L.I64(M), L.I64(H), L.I64(5)) == -1
+    assert L.load().gm_mlp2_hidden_grad_workspace_bytes(L.I64(M), L.I64(96), L.I64(2)) == -1
+
+
 def test_colsum_and_relu_bwd(dev):
     ag = _ag()
     from graphmaker_amd import _lib as L
