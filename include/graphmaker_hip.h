@@ -99,7 +99,9 @@ int gm_spmm_mean(int64_t n, const int32_t* rowptr, const int32_t* colidx, const 
                  float* out, int64_t ldo, gm_stream_t stream);
 
 /* ---- nn.Linear (+ReLU) and nn.LayerNorm as used by model/gnn.py:27-38,116-126,138-142,227-231 ----
- * C[M,N] (ldc) = act(A[M,K] (lda) @ W[N,K]^T (ldw) + bias[N]);  f32 MFMA, k-ascending accumulation. */
+ * C[M,N] (ldc) = act(A[M,K] (lda) @ W[N,K]^T (ldw) + bias[N]);  f32 MFMA, k-ascending accumulation.  The tile
+ * configuration follows the shape (the bits do not: every output is the same ascending-k fmaf chain); N <= 4 over >= 65536
+ * rows (the pair MLP's output layer on a training batch) runs a row-per-lane kernel bound by reading A once. */
 int gm_linear(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw,
               const float* bias, float* C, int64_t ldc, int relu, gm_stream_t stream);
 int gm_layernorm(int64_t M, int64_t N, float* X, int64_t ldx, const float* gamma, const float* beta, float eps,
@@ -258,7 +260,10 @@ int gm_x_from_onehot3d(int64_t n, int64_t F, const float* X_one_hot_3d, uint8_t*
 /* C[m][n] = act( sum_k a(m,k) b(n,k) + bias[n] ), zeroed where mask[m][n] <= 0 (ReLU backward);
  * a(m,k) = a_red ? A[k*lda+m] : A[m*lda+k];  b(n,k) = b_red ? B[k*ldb+n] : B[n*ldb+k].
  * nn.Linear (model/gnn.py:27-38): forward (0,0) A=X B=W; dX = dY W -> (0,1) A=dY B=W; dW = dY^T X -> (1,1) A=dY B=X.
- * Small outputs with a long reduction are split over K into `workspace` and summed in ascending split order. */
+ * Small outputs with a long reduction are split over K into `workspace` and summed in ascending split order; the split
+ * count depends on the shape only (how well tiles x splits fills the chip), so a result is reproducible bit for bit.
+ * (1,1) with M <= 4, N <= 128 and K >= 65536 (the weight gradient of a layer with a few outputs over a pair batch) is a
+ * streaming kernel instead of an MFMA tile. */
 int64_t gm_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int gm_gemm(int a_red, int b_red, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
             int64_t ldb, const float* bias, const float* mask, int64_t ldmask, int relu, float* C, int64_t ldc,
