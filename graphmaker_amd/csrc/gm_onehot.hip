@@ -26,44 +26,56 @@ static OnehotPrep prep_layout(int64_t F, int64_t H) {
     return p;
 }
 
-// B[o], row o of D (zero-padded to ldF) and column o of D^T.  A workgroup owns 64 output units and walks the attributes in
-// tiles of 64: the W tile (64 rows x 128 floats) is read coalesced into LDS; thread o < 64 continues its chain
-// B[o] += W[o][2f] over the tile in ascending f (the oracle's order), and all 256 threads write the tile's D and D^T values
-// coalesced.  (One thread per row reading its own row was 0.35 ms per call -- per training step and tower.)
-constexpr int OP_T = 64;
+// B[o], row o of D (zero-padded to ldF) and column o of D^T.  Two launches: k_onehot_prepare_D gives every 64 x 64 tile of
+// D / D^T its own workgroup (the W tile, 64 rows x 128 floats, is read coalesced into LDS and both layouts leave coalesced);
+// k_onehot_prepare_B continues the chain B[o] += W[o][2f] in ascending f (the oracle's order) with one thread per output unit,
+// 16 units per workgroup, the W tiles staged through LDS the same way.  (One workgroup per 64 units doing all of it tile after
+// tile was 8 workgroups and 0.20 ms per call -- per training step and tower; one thread per row reading its own row 0.35 ms.)
+constexpr int OP_T = 64, OP_BR = 16;
 __global__ void __launch_bounds__(256)
-k_onehot_prepare(int64_t F, int64_t H, int64_t ldF, const float* __restrict__ W, const float* __restrict__ b,
-                 float* __restrict__ B, float* __restrict__ Dt, float* __restrict__ D) {
+k_onehot_prepare_D(int64_t F, int64_t H, int64_t ldF, const float* __restrict__ W, float* __restrict__ Dt, float* __restrict__ D) {
     __shared__ float tile[OP_T][2 * OP_T + 1];
     const int t = threadIdx.x;
-    const int64_t o0 = (int64_t)blockIdx.x * OP_T;
+    const int64_t o0 = (int64_t)blockIdx.x * OP_T, f0 = (int64_t)blockIdx.y * OP_T;
+    for (int e = t; e < OP_T * 2 * OP_T; e += 256) {
+        const int r = e / (2 * OP_T), c = e % (2 * OP_T);
+        const int64_t o = o0 + r, col = 2 * f0 + c;
+        tile[r][c] = (o < H && col < 2 * F) ? W[o * 2 * F + col] : 0.0f;
+    }
+    __syncthreads();
+    for (int e = t; e < OP_T * OP_T; e += 256) {
+        {   // D: k fastest
+            const int r = e / OP_T, k = e % OP_T;
+            const int64_t o = o0 + r, f = f0 + k;
+            if (o < H && f < ldF) D[o * ldF + f] = f < F ? tile[r][2 * k + 1] - tile[r][2 * k] : 0.0f;
+        }
+        {   // D^T: o fastest
+            const int r = e % OP_T, k = e / OP_T;
+            const int64_t o = o0 + r, f = f0 + k;
+            if (o < H && f < F) Dt[f * H + o] = tile[r][2 * k + 1] - tile[r][2 * k];
+        }
+    }
+}
+__global__ void __launch_bounds__(256)
+k_onehot_prepare_B(int64_t F, int64_t H, const float* __restrict__ W, const float* __restrict__ b, float* __restrict__ B) {
+    __shared__ float tile[OP_BR][2 * OP_T + 1];
+    const int t = threadIdx.x;
+    const int64_t o0 = (int64_t)blockIdx.x * OP_BR;
     float acc = 0.0f;
-    for (int64_t f0 = 0; f0 < ldF; f0 += OP_T) {
-        for (int e = t; e < OP_T * 2 * OP_T; e += 256) {
+    for (int64_t f0 = 0; f0 < F; f0 += OP_T) {
+        for (int e = t; e < OP_BR * 2 * OP_T; e += 256) {
             const int r = e / (2 * OP_T), c = e % (2 * OP_T);
             const int64_t o = o0 + r, col = 2 * f0 + c;
             tile[r][c] = (o < H && col < 2 * F) ? W[o * 2 * F + col] : 0.0f;
         }
         __syncthreads();
-        if (t < OP_T) {
+        if (t < OP_BR) {
             const int64_t nf = F - f0 < OP_T ? F - f0 : OP_T;
             for (int64_t k = 0; k < nf; ++k) acc = acc + tile[t][2 * k];
         }
-        for (int e = t; e < OP_T * OP_T; e += 256) {
-            {   // D: k fastest
-                const int r = e / OP_T, k = e % OP_T;
-                const int64_t o = o0 + r, f = f0 + k;
-                if (o < H && f < ldF) D[o * ldF + f] = f < F ? tile[r][2 * k + 1] - tile[r][2 * k] : 0.0f;
-            }
-            {   // D^T: o fastest
-                const int r = e % OP_T, k = e / OP_T;
-                const int64_t o = o0 + r, f = f0 + k;
-                if (o < H && f < F) Dt[f * H + o] = tile[r][2 * k + 1] - tile[r][2 * k];
-            }
-        }
         __syncthreads();
     }
-    if (t < OP_T && o0 + t < H) B[o0 + t] = acc + (b ? b[o0 + t] : 0.0f);
+    if (t < OP_BR && o0 + t < H) B[o0 + t] = acc + (b ? b[o0 + t] : 0.0f);
 }
 
 // X01[v][f] = x[v][f] != 0 as float, rows padded with zeros to ldF (the A operand of the dense form)
@@ -171,8 +183,12 @@ extern "C" int gm_onehot_prepare(int64_t F, int64_t H, const float* W, const flo
     GM_REQUIRE(F > 0 && H > 0 && W && prep, "bad arguments");
     GM_REQUIRE(aligned(prep, 16), "prep must be 16-byte aligned");
     const OnehotPrep p = prep_layout(F, H);
-    hipLaunchKernelGGL(k_onehot_prepare, dim3((unsigned)((H + OP_T - 1) / OP_T)), dim3(256), 0, as_stream(stream), F, H, p.ldF, W, b,
-                       prep + p.oB, prep + p.oDt, prep + p.oD);
+    GM_REQUIRE((p.ldF + OP_T - 1) / OP_T <= 65535, "F too large");
+    hipLaunchKernelGGL(k_onehot_prepare_D, dim3((unsigned)((H + OP_T - 1) / OP_T), (unsigned)((p.ldF + OP_T - 1) / OP_T)), dim3(256), 0,
+                       as_stream(stream), F, H, p.ldF, W, prep + p.oDt, prep + p.oD);
+    GM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_onehot_prepare_B, dim3((unsigned)((H + OP_BR - 1) / OP_BR)), dim3(256), 0, as_stream(stream), F, H, W, b,
+                       prep + p.oB);
     GM_LAUNCH_CHECK();
     return GM_OK;
 }
