@@ -58,8 +58,12 @@ k_spmm_seg(int64_t n, const int32_t* __restrict__ rowptr, const int32_t* __restr
     constexpr int NB = TPR == 8 ? 8 : 4;                // neighbours in flight per lane
     constexpr int PARTS = SW <= 8 ? SP_PARTS : SP_PARTS_WIDE;
     constexpr int SP_ITEMS = SP_RB + PARTS;
-    __shared__ int idx_s[NG][SP_SEG];
-    __shared__ float w_s[TRANSPOSED ? NG : 1][SP_SEG];
+    // column indices (and, transposed, neighbour weights): a slot of SP_SEG per group -- or, when the workgroup's rows have at
+    // most SP_PRE neighbours in all (their colidx ranges are one contiguous piece), all of them, read in ONE coalesced pass
+    // before the item loop instead of one dependent global read per item
+    constexpr int SP_PRE = NG * SP_SEG;                 // 2048 for the 128-byte slabs; the 2 KB-slab variant keeps its 256
+    __shared__ int idx_s[SP_PRE];
+    __shared__ float w_s[TRANSPOSED ? SP_PRE : 1];
     __shared__ float4 part_s[PARTS][SW];
     __shared__ int row_b[SP_RB], row_e[SP_RB], row_slot[SP_RB], row_nseg[SP_RB];
     __shared__ unsigned short item_row[SP_ITEMS], item_seg[SP_ITEMS];
@@ -152,6 +156,17 @@ k_spmm_seg(int64_t n, const int32_t* __restrict__ rowptr, const int32_t* __restr
     }
     __syncthreads();
     const int nitems = nitems_s;
+    const int64_t ilast = i0 + SP_RB < n ? i0 + SP_RB : n;
+    const int pre_base = row_b[0], pre_cnt = row_e[(int)(ilast - i0) - 1] - pre_base;
+    const bool pre = pre_cnt <= SP_PRE;
+    if (pre) {
+        for (int e = tid; e < pre_cnt; e += 256) {
+            const int j = colidx[pre_base + e];
+            idx_s[e] = j;
+            if (TRANSPOSED) w_s[e] = 1.0f / (float)(rowptr[j + 1] - rowptr[j]);
+        }
+        __syncthreads();
+    }
 
     for (;;) {
         int it = 0;
@@ -170,14 +185,17 @@ k_spmm_seg(int64_t n, const int32_t* __restrict__ rowptr, const int32_t* __restr
         for (int ps = p0; ps < p1 || ps == p0; ps += SP_SEG) {          // one pass unless SP_SERIAL (an empty row: one pass of nothing)
             const int pe = ps + SP_SEG < p1 ? ps + SP_SEG : p1;
             const int cnt = pe - ps;
-            // the segment's column indices: one coalesced read by the 8 lanes into the group's LDS slot
+            // the segment's column indices: already in LDS, or one coalesced read by the group's lanes into its LDS slot
+            const int ib = pre ? ps - pre_base : g * SP_SEG;
+            if (!pre) {
 #pragma unroll
-            for (int q = 0; q < (SP_SEG + TPR - 1) / TPR; ++q) {
-                const int k = l + TPR * q;
-                if (k < cnt) {
-                    const int j = colidx[ps + k];
-                    idx_s[g][k] = j;
-                    if (TRANSPOSED) w_s[g][k] = 1.0f / (float)(rowptr[j + 1] - rowptr[j]);
+                for (int q = 0; q < (SP_SEG + TPR - 1) / TPR; ++q) {
+                    const int k = l + TPR * q;
+                    if (k < cnt) {
+                        const int j = colidx[ps + k];
+                        idx_s[ib + k] = j;
+                        if (TRANSPOSED) w_s[ib + k] = 1.0f / (float)(rowptr[j + 1] - rowptr[j]);
+                    }
                 }
             }
             float4 acc[CH];
@@ -189,11 +207,11 @@ k_spmm_seg(int64_t n, const int32_t* __restrict__ rowptr, const int32_t* __restr
 #pragma unroll
                 for (int q = 0; q < NB; ++q) {
                     const bool in = k + q < cnt;
-                    int j = in ? idx_s[g][k + q] : 0;
+                    int j = in ? idx_s[ib + k + q] : 0;
 #ifdef GM_SPMM_X_SCRAMBLE   // exploration: same structure, gather targets spread uniformly (wrong results) -- isolates hot-row effects
                     j = (int)(((uint32_t)j * 2654435761u) % (uint32_t)n);
 #endif
-                    w[q] = TRANSPOSED ? (in ? w_s[g][k + q] : 0.0f) : inv_row;
+                    w[q] = TRANSPOSED ? (in ? w_s[ib + k + q] : 0.0f) : inv_row;
 #pragma unroll
                     for (int c = 0; c < CH; ++c)
                         v[q][c] = (in && on[c]) ? *reinterpret_cast<const float4*>(src[c] + (int64_t)j * ldh)
