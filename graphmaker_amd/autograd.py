@@ -64,11 +64,26 @@ def colsum(X):
     return out
 
 
+def _dy_w(g, W, M, K, N, mask=None):
+    """dY W (M x K, reduced over W's N rows), zero where mask <= 0.  Wide layers over many rows go through the forward
+    kernel with a transposed copy of W: gm_linear's 16-wave tile runs 13752 x 1744 x 1744 at 112 TFLOP/s where gm_gemm(0,1)
+    reaches 96 (1744 x 1534: 112 vs 78), the copy costs 0.03 ms, and both walk the reduced dimension in ascending order
+    from 0 -- the same bits wherever gm_gemm would not split the reduction, as on the tower shapes (tools/dx_ab.py)."""
+    if M >= 4096 and N >= 1024 and K >= 1024:
+        Wt = W.t().contiguous()
+        out = torch.empty((M, K), dtype=torch.float32, device=g.device)
+        L.call("gm_linear", I64(M), I64(K), I64(N), ptr(g), I64(N), ptr(Wt), I64(N), None, ptr(out), I64(K), I32(0), stream_ptr())
+        if mask is not None:
+            L.call("gm_relu_bwd", I64(out.numel()), ptr(out), ptr(mask), ptr(out), stream_ptr())
+        return out
+    return gemm(False, True, M, K, N, g, N, W, K, mask=mask)
+
+
 def _linear_backward(x, W, g, needs):
     """(dx, dW, db) of y = x W^T + b for the gradient g of y (already masked by any ReLU)."""
     M, K = x.shape
     N = W.shape[0]
-    dx = gemm(False, True, M, K, N, g, N, W, K) if needs[0] else None             # dY W
+    dx = _dy_w(g, W, M, K, N) if needs[0] else None                               # dY W
     dW = gemm(True, True, N, K, M, g, N, x, K) if needs[1] else None              # dY^T X
     db = colsum(g) if needs[2] else None
     return dx, dW, db
@@ -157,7 +172,7 @@ class _Mlp2(torch.autograd.Function):
                    I64(ws.numel() if ws is not None else 0), stream_ptr())
             dx, dW1, _ = _linear_backward(x, W1, g1, (need[0], need[1], False))
         else:
-            g1 = gemm(False, True, M, H, N, g, N, W2, H, mask=y1)          # (dY W2) where the hidden unit was active
+            g1 = _dy_w(g, W2, M, H, N, mask=y1)                            # (dY W2) where the hidden unit was active
             dx, dW1, db1 = _linear_backward(x, W1, g1, (need[0], need[1], want_db1))
         return dx, dW1, db1, dW2, db2, None, None
 

@@ -120,6 +120,26 @@ def test_mlp2_hidden_grad_fused(dev, M, H, N):
     assert L.load().gm_mlp2_hidden_grad_workspace_bytes(L.I64(M), L.I64(96), L.I64(2)) == -1
 
 
+def test_wide_input_gradient_through_the_forward_kernel(dev):
+    """autograd._dy_w: dY W of a wide layer over many rows runs gm_linear on a transposed copy of W; it must give the bits
+    of gm_gemm(0,1) where that kernel does not split the reduction (>= 512 output tiles; both then walk the reduced dimension
+    in ascending order from 0), with and without the ReLU mask."""
+    ag = _ag()
+    g = torch.Generator().manual_seed(11)
+    M, K, N = 8200, 1030, 1100
+    gy = torch.randn(M, N, generator=g).to(dev)
+    W = (torch.randn(N, K, generator=g) / N ** 0.5).to(dev)
+    mask = torch.randn(M, K, generator=g).to(dev)
+    for m in (None, mask):
+        want = ag.gemm(False, True, M, K, N, gy, N, W, K, mask=m)
+        got = ag._dy_w(gy, W, M, K, N, mask=m)
+        assert torch.equal(got, want)
+    ref = gy.double() @ W.double()
+    _close(ag._dy_w(gy, W, M, K, N).cpu().numpy(), ref.cpu().numpy(), 2e-5 * float(ref.abs().max()), 1e-5, "dY W")
+    small = ag._dy_w(gy[:100].contiguous(), W, 100, K, N)                 # below the thresholds: the general kernel
+    assert torch.equal(small, ag.gemm(False, True, 100, K, N, gy[:100].contiguous(), N, W, K))
+
+
 def test_colsum_and_relu_bwd(dev):
     ag = _ag()
     from graphmaker_amd import _lib as L
