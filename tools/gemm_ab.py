@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B timing of gm_linear across library builds for the tower GEMM shapes (exploration tool; GPU box).
-usage: python tools/gemm_ab.py [--m M1,M2,...] libA.so libB.so ...   (outputs of every library are compared bit for bit with the first one's)"""
+usage: python tools/gemm_ab.py [--m M1,M2,...] [--nk "N,K;N,K"] libA.so libB.so ...   (outputs of every library are compared bit for bit with the first one's)"""
 import ctypes as C, os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dev = torch.device("cuda:0")
@@ -9,7 +9,11 @@ MS = [13752]
 if argv and argv[0] == "--m":
     MS = [int(x) for x in argv[1].split(",")]
     argv = argv[2:]
-SHAPES = [(M, n, k) for M in MS for (n, k) in [(512, 1534), (512, 512), (512, 592), (1744, 1744), (128, 1744), (1534, 1744), (767, 1744), (64, 64)]]
+NK = None
+if argv and argv[0] == "--nk":          # e.g. --nk 128,128;2,128
+    NK = [tuple(int(v) for v in x.split(",")) for x in argv[1].split(";")]
+    argv = argv[2:]
+SHAPES = [(M, n, k) for M in MS for (n, k) in NK] if NK else [(M, n, k) for M in MS for (n, k) in [(512, 1534), (512, 512), (512, 592), (1744, 1744), (128, 1744), (1534, 1744), (767, 1744), (64, 64)]]
 libs = [(p, C.CDLL(os.path.join(ROOT, p))) for p in argv]
 tot = {p: 0.0 for p, _ in libs}
 for (M, N, K) in SHAPES:
