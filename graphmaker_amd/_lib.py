@@ -21,7 +21,7 @@ EXPORTS = [
     "gm_noise_E", "gm_noise_X", "gm_bitmap_from_onehot_f32", "gm_x_from_onehot3d",
     "gm_gemm_workspace_bytes", "gm_gemm", "gm_mlp2_hidden_grad_workspace_bytes", "gm_mlp2_hidden_grad", "gm_colsum_workspace_bytes", "gm_colsum", "gm_layernorm_fwd",
     "gm_layernorm_bwd_workspace_bytes", "gm_layernorm_bwd", "gm_spmm_mean_bwd", "gm_embedding_bwd_workspace_bytes", "gm_embedding_bwd",
-    "gm_hadamard_gather_bwd", "gm_softmax_ce2_workspace_bytes", "gm_softmax_ce2",
+    "gm_hadamard_gather_bwd", "gm_softmax_ce2_workspace_bytes", "gm_softmax_ce2", "gm_ce2_diff", "gm_head_diff_bwd",
     "gm_relu_bwd", "gm_dropout", "gm_embedding_fwd", "gm_denoise_match2", "gm_bitmap_lookup",
     "gm_triangles_per_node", "gm_same_class_degree", "gm_bitmap_square", "gm_class_bitmaps", "gm_masked_degree",
 ]

@@ -322,6 +322,55 @@ class _SoftmaxCE2(torch.autograd.Function):
         return dl * g, None
 
 
+class _CE2Diff(torch.autograd.Function):
+    """Two-class cross entropy from the logit difference d = l1 - l0 (gm_ce2_diff)."""
+
+    @staticmethod
+    def forward(ctx, diff, target_u8):
+        diff = _c(diff)
+        require(diff, torch.float32, "diff")
+        require(target_u8, torch.uint8, "target")
+        total = target_u8.numel()
+        if diff.numel() != total:
+            raise ValueError(f"ce2_diff: {diff.numel()} differences for {total} targets")
+        dev = diff.device
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        dd = torch.empty_like(diff) if ctx.needs_input_grad[0] else None
+        ws = _scratch(L.load().gm_softmax_ce2_workspace_bytes(), dev, slot=1)
+        L.call("gm_ce2_diff", I64(total), ptr(diff), ptr(target_u8), ptr(loss), ptr(dd), ptr(ws), I64(ws.numel()), stream_ptr())
+        ctx.save_for_backward(dd)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dd,) = ctx.saved_tensors
+        return dd * g, None
+
+
+class _HeadDiff(torch.autograd.Function):
+    """(Wd, bd) = (W[1::2] - W[0::2], b[1::2] - b[0::2]) of a two-class head (gm_head_diff_prepare); the gradient goes back
+    as dW[1::2] = dWd, dW[0::2] = -dWd (gm_head_diff_bwd)."""
+
+    @staticmethod
+    def forward(ctx, W, b):
+        W, b = _c(W), _c(b)
+        Wd, bd = ops.head_diff(W, b)
+        ctx.shape = tuple(W.shape)
+        return Wd, bd
+
+    @staticmethod
+    def backward(ctx, gWd, gbd):
+        F2, Hc = ctx.shape
+        if gWd is None:
+            gWd = torch.zeros((F2 // 2, Hc), dtype=torch.float32, device=gbd.device)
+        gWd = _c(gWd)
+        gbd = _c(gbd) if gbd is not None else None
+        dW = torch.empty((F2, Hc), dtype=torch.float32, device=gWd.device)
+        db = torch.empty(F2, dtype=torch.float32, device=gWd.device) if gbd is not None else None
+        L.call("gm_head_diff_bwd", I64(F2 // 2), I64(Hc), ptr(gWd), ptr(gbd), ptr(dW), ptr(db), stream_ptr())
+        return dW, db
+
+
 class _Dropout(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, p, seed, call):
@@ -368,6 +417,14 @@ def hadamard_gather(h, src, dst):
 
 def softmax_ce2(logits, target_u8):
     return _SoftmaxCE2.apply(logits, target_u8)
+
+
+def ce2_diff(diff, target_u8):
+    return _CE2Diff.apply(diff, target_u8)
+
+
+def head_diff(W, b):
+    return _HeadDiff.apply(W, b)
 
 
 class DropoutState:

@@ -494,6 +494,44 @@ k_softmax_ce2(int64_t total, const float* __restrict__ logits, const uint8_t* __
     if (threadIdx.x == 0) part[blockIdx.x] = (((red[0] + red[1]) + red[2]) + red[3]) * inv_total;
 }
 
+// ---- the same loss from the logit DIFFERENCE d = l1 - l0 (attribute head folded by gm_head_diff_prepare):
+//      CE = log(1 + exp(-|d|)) + max(-s, 0), s = target ? d : -d;   dCE/dd = (sigmoid(d) - target) / total.
+// Same fixed grid and summation order as k_softmax_ce2.
+__global__ void __launch_bounds__(256)
+k_ce2_diff(int64_t total, const float* __restrict__ diff, const uint8_t* __restrict__ target, float inv_total,
+           float* __restrict__ part, float* __restrict__ ddiff) {
+    __shared__ float red[4];
+    float acc = 0.0f;
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)CE_BLOCKS * 256) {
+        const float d = diff[g];
+        const bool y = target[g] != 0, pos = d > 0.0f;
+        const float e = expf_nonpos(pos ? -d : d);                 // exp(-|d|): the smaller class against the larger
+        const float s = 1.0f + e;
+        const float sgn = y ? d : -d;
+        acc = acc + (__logf(s) + (sgn < 0.0f ? -sgn : 0.0f));
+        if (ddiff) {
+            const float p1 = pos ? 1.0f / s : e / s;               // sigmoid(d)
+            ddiff[g] = (p1 - (y ? 1.0f : 0.0f)) * inv_total;
+        }
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (((red[0] + red[1]) + red[2]) + red[3]) * inv_total;
+}
+
+// gradient of the folded head back to mlp_out.2: dW[2f+1] = dWd[f], dW[2f] = -dWd[f] (exact), the same for the bias
+__global__ void k_head_diff_bwd(int64_t F, int64_t Hc, const float* __restrict__ dWd, const float* __restrict__ dbd,
+                                float* __restrict__ dW, float* __restrict__ db) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= F * Hc) return;
+    const int64_t f = g / Hc, k = g - f * Hc;
+    const float v = dWd[g];
+    dW[(2 * f + 1) * Hc + k] = v;
+    dW[2 * f * Hc + k] = -v;
+    if (g < F && db) { db[2 * g + 1] = dbd[g]; db[2 * g] = -dbd[g]; }
+}
+
 // ---- elementwise pieces of the tape
 __global__ void k_relu_bwd(int64_t total, const float* __restrict__ g, const float* __restrict__ y, float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -794,6 +832,27 @@ extern "C" int gm_softmax_ce2(int64_t total, const float* logits, const uint8_t*
     hipLaunchKernelGGL(k_softmax_ce2, dim3(CE_BLOCKS), dim3(256), 0, s, total, logits, target, 1.0f / (float)total, part, dlogits);
     GM_LAUNCH_CHECK();
     return launch_reduce(CE_BLOCKS, 1, 1, part, nullptr, nullptr, 0, 0, loss, 1, s);
+}
+
+extern "C" int gm_ce2_diff(int64_t total, const float* diff, const uint8_t* target, float* loss, float* ddiff, void* workspace,
+                           int64_t workspace_bytes, gm_stream_t stream) {
+    GM_REQUIRE(total > 0 && diff && target && loss, "bad arguments");
+    GM_REQUIRE(workspace && workspace_bytes >= CE_BLOCKS * 4, "gm_ce2_diff needs %d workspace bytes", CE_BLOCKS * 4);
+    hipStream_t s = as_stream(stream);
+    float* part = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(k_ce2_diff, dim3(CE_BLOCKS), dim3(256), 0, s, total, diff, target, 1.0f / (float)total, part, ddiff);
+    GM_LAUNCH_CHECK();
+    return launch_reduce(CE_BLOCKS, 1, 1, part, nullptr, nullptr, 0, 0, loss, 1, s);
+}
+
+extern "C" int gm_head_diff_bwd(int64_t F, int64_t Hc, const float* dWd, const float* dbd, float* dW, float* db,
+                                gm_stream_t stream) {
+    GM_REQUIRE(F > 0 && Hc > 0 && dWd && dW && (!db || dbd), "bad arguments");
+    GM_REQUIRE(F * Hc < (1ll << 39), "F*Hc too large");
+    hipLaunchKernelGGL(k_head_diff_bwd, dim3((unsigned)((F * Hc + 255) / 256)), dim3(256), 0, as_stream(stream), F, Hc, dWd, dbd, dW,
+                       db);
+    GM_LAUNCH_CHECK();
+    return GM_OK;
 }
 
 extern "C" int gm_relu_bwd(int64_t total, const float* g, const float* y, float* out, gm_stream_t stream) {

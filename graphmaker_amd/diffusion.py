@@ -430,8 +430,12 @@ class ModelSync(BaseModel):
         x0, _ = self._real_state(X_one_hot_3d, E_one_hot)
         _, t_float, _, x_t_onehot, bits_t = self._apply_noise_state(X_one_hot_3d, E_one_hot, t, seed, uniforms)
         A_t = ops.adjacency_from_bitmap(bits_t, self.num_nodes)
-        logit_X, logit_E = self.graph_encoder(t_float, x_t_onehot, Y, A_t, batch_src, batch_dst)
-        loss_X = ag.softmax_ce2(logit_X, x0)                                         # LossX :474-515
+        # GNN.forward (model/gnn.py:330-334) in two calls: the two-class attribute loss is a function of l1 - l0 only, so the
+        # node tower runs with its head folded to the difference (half of the head's GEMMs, forward and backward)
+        ge = self.graph_encoder
+        diff_X = ge.pred_X._run(t_float, x_t_onehot, Y, A_t, diff_head=True)
+        logit_E = ge.pred_E(t_float, x_t_onehot, Y, A_t, batch_src, batch_dst)
+        loss_X = ag.ce2_diff(diff_X, x0)                                             # LossX :474-515
         loss_E = ag.softmax_ce2(logit_E, self._edge_targets(batch_E_one_hot))        # LossE :120-141
         return loss_X, loss_E
 
@@ -635,8 +639,10 @@ class ModelAsync(BaseModel):
         _, t_float_X, _, x_t_onehot = self._apply_noise_X_state(X_one_hot_3d, t_X, seed, uni.get("X"))
         _, t_float_E, bits_t = self._apply_noise_E_state(E_one_hot, t_E, seed, uni.get("E"))
         A_t = ops.adjacency_from_bitmap(bits_t, self.num_nodes)
-        logit_X, logit_E = self.graph_encoder(t_float_X, t_float_E, x_t_onehot, Y, X_one_hot_2d, A_t, batch_src, batch_dst)
-        loss_X = ag.softmax_ce2(logit_X, x0)
+        ge = self.graph_encoder      # GNNAsymm.forward (model/gnn.py:545-550) in two calls, the attribute head folded as in ModelSync
+        diff_X = ge.pred_X._run(t_float_X, x_t_onehot, Y, None, diff_head=True)
+        logit_E = ge.pred_E(t_float_E, X_one_hot_2d, Y, A_t, batch_src, batch_dst)
+        loss_X = ag.ce2_diff(diff_X, x0)
         loss_E = ag.softmax_ce2(logit_E, self._edge_targets(batch_E_one_hot))
         return loss_X, loss_E
 

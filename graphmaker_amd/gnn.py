@@ -140,8 +140,10 @@ class _TowerBase(nn.Module):
     def _on_tape(self):
         return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
 
-    def _run_tape(self, t_float, X_t_one_hot, Y_real, A_t):
-        """The tower operator by operator with autograd recording (model/gnn.py:146-176 / :440-463); returns (n, out)."""
+    def _run_tape(self, t_float, X_t_one_hot, Y_real, A_t, diff_head=False):
+        """The tower operator by operator with autograd recording (model/gnn.py:146-176 / :440-463); returns (n, out).
+        diff_head: the last Linear folded to the logit difference per attribute, (n, F) -- what a two-class cross entropy
+        needs (half of the head's GEMMs forward and backward); the gradient reaches mlp_out.2 through autograd.head_diff."""
         def lin(m, x, relu):
             return ag.linear(x, m.weight, m.bias, relu)
 
@@ -174,6 +176,12 @@ class _TowerBase(nn.Module):
             hX_list.append(h_X)
             hY_list.append(h_Y)
         h_cat = torch.cat(hX_list + hY_list + [h_t_exp], dim=1)
+        if diff_head:
+            if self.num_classes_X != 2 or self._dims.out_size != 2 * self.num_attrs_X:
+                raise ValueError("the logit-difference head needs a two-class attribute head (out_size = 2 * num_attrs_X)")
+            mo = self.mlp_out
+            Wd, bd = ag.head_diff(mo[2].weight, mo[2].bias)
+            return ag.mlp2(h_cat, mo[0].weight, mo[0].bias, Wd, bd, False)
         return mlp2(self.mlp_out, h_cat, False)
 
     def _run(self, t_float, X_t_one_hot, Y_real, A_t, want_hcat=False, rows=None, out=None, reuse_X=False, x_u8=None,
@@ -181,8 +189,8 @@ class _TowerBase(nn.Module):
         """reuse_X: the caller guarantees that X_t_one_hot, the parameters and the node count are those of the previous
         fused call of THIS tower, so mlp_in_X(X) is taken from the tower's workspace (ModelAsync's structure steps).
         diff_head: return the (n, F) logit differences of _head(True) instead of the (n, 2F) logits (sampling only)."""
-        if self._on_tape() and not want_hcat and rows is None and out is None and not diff_head:
-            return self._run_tape(t_float, X_t_one_hot, Y_real, A_t)
+        if self._on_tape() and not want_hcat and rows is None and out is None:
+            return self._run_tape(t_float, X_t_one_hot, Y_real, A_t, diff_head=diff_head)
         if self.training and any(m.p > 0 for m in self.modules() if isinstance(m, nn.Dropout)):
             raise NotImplementedError("the fused tower call has no dropout: use train mode with autograd enabled, or eval()")
         n = X_t_one_hot.shape[0]

@@ -301,6 +301,14 @@ int gm_hadamard_gather_bwd(int64_t n, int64_t B, int64_t d, const int64_t* src, 
                            const int64_t* segptr, const int64_t* order, const float* h, int64_t ldh, const float* dZ,
                            int64_t lddz, float* dh, int64_t lddh, gm_stream_t stream);
 /* out = g where y > 0 else 0 (nn.ReLU backward, model/gnn.py:29,35,118,124,140) */
+/* The attribute loss from the logit difference (LossX, model/diffusion.py:474-515, for two classes): a training step may run the
+ * node tower with the folded head of gm_head_diff_prepare (half of its output GEMM forward and backward), since
+ * CE(softmax([l0,l1]), y) = log(1 + exp(-|d|)) + max(-s, 0) with d = l1 - l0, s = y ? d : -d.  loss (1 float) = mean over
+ * `total` items, ddiff (optional) = d loss / d diff; workspace as gm_softmax_ce2.  gm_head_diff_bwd maps the gradient of the
+ * folded head back to mlp_out.2: dW[2f+1] = dWd[f], dW[2f] = -dWd[f], likewise the bias (db / dbd may be NULL). */
+int gm_ce2_diff(int64_t total, const float* diff, const uint8_t* target, float* loss, float* ddiff, void* workspace,
+                int64_t workspace_bytes, gm_stream_t stream);
+int gm_head_diff_bwd(int64_t F, int64_t Hc, const float* dWd, const float* dbd, float* dW, float* db, gm_stream_t stream);
 int gm_relu_bwd(int64_t total, const float* g, const float* y, float* out, gm_stream_t stream);
 /* nn.Dropout (model/gnn.py:31,37) in training mode: out = x/(1-p) where u >= p else 0, u = Philox stream 7 at element
  * index with counter word `call`; the same (seed, call) applied to the gradient is the backward */

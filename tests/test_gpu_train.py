@@ -270,6 +270,38 @@ def test_embedding_hadamard_ce_backward(dev):
     _close(ld.grad.cpu().numpy(), lc.grad.numpy(), 1e-9, 1e-5, "cross entropy backward")
 
 
+def test_ce2_from_logit_difference_and_folded_head_backward(dev):
+    """gm_ce2_diff == two-class cross entropy of [l0, l1] as a function of d = l1 - l0 (value and gradient, against torch in
+    float64); autograd.head_diff: forward = W[1::2] - W[0::2], backward = (+g, -g) interleaved, exactly."""
+    ag = _ag()
+    g = torch.Generator().manual_seed(21)
+    logits = torch.randn(7001, 2, generator=g) * 4
+    logits[:5] = torch.tensor([[0.0, 0.0], [90.0, -90.0], [-90.0, 90.0], [1e-8, 0.0], [-3.0, -3.0]])
+    tgt = torch.randint(0, 2, (7001,), generator=g)
+    lc = logits.double().clone().requires_grad_(True)
+    ref = F.cross_entropy(lc, tgt)
+    ref.backward()
+    d = (logits[:, 1] - logits[:, 0]).to(dev).requires_grad_(True)
+    loss = ag.ce2_diff(d, tgt.to(torch.uint8).to(dev))
+    (loss * 2.0).backward()
+    d64 = (logits[:, 1] - logits[:, 0]).double().requires_grad_(True)       # the f32 difference as the exact input
+    ref_d = F.cross_entropy(torch.stack([torch.zeros_like(d64), d64], 1), tgt)
+    ref_d.backward()
+    assert abs(loss.item() - ref_d.item()) <= 2e-6 * abs(ref_d.item())
+    _close(d.grad.cpu().numpy(), 2.0 * d64.grad.numpy(), 1e-10, 2e-5, "d CE / d diff")
+    assert abs(ref.item() - ref_d.item()) < 1e-6                                  # the two forms agree (up to the f32 subtraction)
+
+    Fh, Hc = 37, 53
+    W = torch.randn(2 * Fh, Hc, generator=g).to(dev).requires_grad_(True)
+    b = torch.randn(2 * Fh, generator=g).to(dev).requires_grad_(True)
+    Wd, bd = ag.head_diff(W, b)
+    assert torch.equal(Wd, W[1::2] - W[0::2]) and torch.equal(bd, b[1::2] - b[0::2])
+    gW, gb = torch.randn(Fh, Hc, generator=g).to(dev), torch.randn(Fh, generator=g).to(dev)
+    ((Wd * gW).sum() + (bd * gb).sum()).backward()
+    assert torch.equal(W.grad[1::2], gW) and torch.equal(W.grad[0::2], -gW)
+    assert torch.equal(b.grad[1::2], gb) and torch.equal(b.grad[0::2], -gb)
+
+
 def test_dropout_mask_is_reproducible(dev):
     ag = _ag()
     x = torch.ones(200000, device=dev, requires_grad=True)
