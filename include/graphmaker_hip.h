@@ -214,7 +214,7 @@ int gm_attr_posterior_sample(int64_t n, int64_t F, const float* logits, const ui
  * node tower's output, so it runs the tower with the half-width head of gm_head_diff_prepare in place of mlp_out.2
  * (out_size = F instead of 2F: half of the tower's largest GEMM) and calls this entry.  diff differs from the difference
  * of the two rounded logits by f32 rounding only (same order as the GEMM's own); the oracle computes it the same way.
- * Training and forward() keep the two-logit head. */
+ * forward() keeps the two-logit head; the training loss uses the difference too (gm_ce2_diff below). */
 int gm_attr_posterior_sample_diff(int64_t n, int64_t F, const float* diff, const uint8_t* x_t, const float* tab,
                                   const float* u, uint64_t seed, uint32_t step, int64_t v_begin, int64_t v_end,
                                   uint8_t* x_s, float* onehot_out, float* post_dbg, gm_stream_t stream);
