@@ -97,16 +97,29 @@ __global__ void k_prior_Y(int64_t n, int C, const float* __restrict__ Ym, const 
     y[v] = pick;
 }
 
+// grid and draw sharing as in k_attr_posterior_sample: four nodes per thread, one Philox block per four draws
 __global__ void k_prior_X(int64_t n, int64_t F, const float* __restrict__ Xm, const float* __restrict__ u, uint64_t seed,
                           uint8_t* __restrict__ x, float* __restrict__ onehot) {
-    const int64_t v = blockIdx.x, f = (int64_t)blockIdx.y * blockDim.x + threadIdx.x;   // x = node row, y = attribute chunk
+    const int64_t f = (int64_t)blockIdx.y * blockDim.x + threadIdx.x;
     if (f >= F) return;
-    const int64_t g = v * F + f;
-    const int64_t idx = f * n + v;
-    const float uu = u ? u[idx] : u_idx64(seed, 0u, STREAM_X, (uint64_t)idx);
-    const bool b = draw2(uu, Xm[2 * f], Xm[2 * f + 1]);
-    x[g] = b ? 1 : 0;
-    if (onehot) *reinterpret_cast<float2*>(onehot + 2 * g) = b ? make_float2(0.f, 1.f) : make_float2(1.f, 0.f);
+    const int64_t base = f * n, s = base & 3;
+    const int64_t v0 = (int64_t)blockIdx.x * 4 - s;
+    u32x4 o;
+    if (!u) {
+        const uint64_t q = (uint64_t)(base + v0) >> 2;
+        o = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), 0u, STREAM_X, (uint32_t)seed, (uint32_t)(seed >> 32));
+    }
+    const float m0 = Xm[2 * f], m1 = Xm[2 * f + 1];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t v = v0 + k;
+        if (v < 0 || v >= n) continue;
+        const int64_t g = v * F + f;
+        const float uu = u ? u[base + v] : u01(o.v[k]);
+        const bool b = draw2(uu, m0, m1);
+        x[g] = b ? 1 : 0;
+        if (onehot) *reinterpret_cast<float2*>(onehot + 2 * g) = b ? make_float2(0.f, 1.f) : make_float2(1.f, 0.f);
+    }
 }
 
 // upper[i][w] bits j >= i (diagonal included), one thread per word
@@ -206,8 +219,8 @@ extern "C" int gm_prior_X(int64_t n, int64_t F, const float* X_marginal, const f
     GM_REQUIRE(n > 0 && F > 0 && X_marginal && x, "bad arguments");
     GM_REQUIRE(!onehot_out || aligned(onehot_out, 8), "onehot must be 8-byte aligned");
     GM_REQUIRE(n < (1ll << 31) && (F + 255) / 256 <= 65535, "grid too large");
-    hipLaunchKernelGGL(k_prior_X, dim3((unsigned)n, (unsigned)((F + 255) / 256)), dim3(256), 0, as_stream(stream), n, F, X_marginal, u, seed, x,
-                       onehot_out);
+    hipLaunchKernelGGL(k_prior_X, dim3((unsigned)(((n + 2) >> 2) + 1), (unsigned)((F + 255) / 256)), dim3(256), 0, as_stream(stream), n, F,
+                       X_marginal, u, seed, x, onehot_out);
     GM_LAUNCH_CHECK();
     return GM_OK;
 }

@@ -42,18 +42,32 @@ __global__ void k_noise_E_upper(int64_t n, int64_t wpr, const uint32_t* __restri
     upper[g] = word;
 }
 
+// grid: x = group of four nodes, y = 256-attribute chunk; a thread takes the four nodes whose draw indices f*n + v share one
+// Philox block (as k_attr_posterior_sample in gm_attr.hip): one block per four draws, same values as u_idx64
 __global__ void k_noise_X(int64_t n, int64_t F, const uint8_t* __restrict__ x0, const float* __restrict__ QX,
                           const float* __restrict__ u, uint64_t seed, uint32_t step, uint8_t* __restrict__ x_t,
                           float* __restrict__ onehot) {
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n * F) return;
-    const int64_t v = g / F, f = g % F;
-    const int64_t idx = f * n + v;
-    const float uu = u ? u[idx] : u_idx64(seed, step, STREAM_X_NOISE, (uint64_t)idx);
-    const int r = x0[g] ? 1 : 0;
-    const bool b = draw2(uu, QX[4 * f + 2 * r], QX[4 * f + 2 * r + 1]);
-    x_t[g] = b ? 1 : 0;
-    if (onehot) *reinterpret_cast<float2*>(onehot + 2 * g) = b ? make_float2(0.f, 1.f) : make_float2(1.f, 0.f);
+    const int64_t f = (int64_t)blockIdx.y * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const int64_t base = f * n, s = base & 3;
+    const int64_t v0 = (int64_t)blockIdx.x * 4 - s;
+    u32x4 o;
+    if (!u) {
+        const uint64_t q = (uint64_t)(base + v0) >> 2;
+        o = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), step, STREAM_X_NOISE, (uint32_t)seed, (uint32_t)(seed >> 32));
+    }
+    const float q00 = QX[4 * f], q01 = QX[4 * f + 1], q10 = QX[4 * f + 2], q11 = QX[4 * f + 3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t v = v0 + k;
+        if (v < 0 || v >= n) continue;
+        const int64_t g = v * F + f;
+        const float uu = u ? u[base + v] : u01(o.v[k]);
+        const bool r = x0[g] != 0;
+        const bool b = draw2(uu, r ? q10 : q00, r ? q11 : q01);
+        x_t[g] = b ? 1 : 0;
+        if (onehot) *reinterpret_cast<float2*>(onehot + 2 * g) = b ? make_float2(0.f, 1.f) : make_float2(1.f, 0.f);
+    }
 }
 
 // one thread per output word; channel 1 > channel 0 marks an edge (one-hot input)
@@ -103,8 +117,9 @@ extern "C" int gm_noise_X(int64_t n, int64_t F, const uint8_t* x0, const float* 
     GM_REQUIRE(n > 0 && F > 0 && x0 && Q_bar_t_X && x_t, "bad arguments");
     GM_REQUIRE(!onehot_out || aligned(onehot_out, 8), "onehot must be 8-byte aligned");
     GM_REQUIRE(n * F < (1ll << 39), "n*F too large");
-    hipLaunchKernelGGL(k_noise_X, dim3(blocks_for(n * F)), dim3(256), 0, as_stream(stream), n, F, x0, Q_bar_t_X, u, seed, step,
-                       x_t, onehot_out);
+    GM_REQUIRE((n + 2) / 4 + 1 < (1ll << 31) && (F + 255) / 256 <= 65535, "grid too large");
+    hipLaunchKernelGGL(k_noise_X, dim3((unsigned)(((n + 2) >> 2) + 1), (unsigned)((F + 255) / 256)), dim3(256), 0, as_stream(stream), n, F,
+                       x0, Q_bar_t_X, u, seed, step, x_t, onehot_out);
     GM_LAUNCH_CHECK();
     return GM_OK;
 }
