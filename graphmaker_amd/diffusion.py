@@ -134,7 +134,8 @@ class BaseModel(nn.Module):
         enqueued on) when profiling is on; free otherwise."""
 
         def __init__(self, model, name):
-            self.rec = model._prof
+            only = model.__dict__.get("_prof_only")
+            self.rec = model._prof if only is None or name in only else None
             self.name = name
 
         def __enter__(self):
@@ -203,8 +204,11 @@ class BaseModel(nn.Module):
             st = self.__dict__["_side"] = torch.cuda.Stream(device=device, priority=0)
         return st
 
-    def enable_phase_timing(self, on=True):
+    def enable_phase_timing(self, on=True, only=None):
+        """only: names of the phases to bracket (every event record is a barrier in the stream, about 5-10 us of GPU idle
+        time: a step with all of its phases bracketed runs measurably slower than the product's step)."""
         self._prof = {} if on else None
+        self.__dict__["_prof_only"] = set(only) if (on and only is not None) else None
 
     def phase_times_ms(self):
         """{phase: [ms per occurrence]}; call after torch.cuda.synchronize()."""
