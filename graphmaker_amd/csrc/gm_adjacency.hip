@@ -269,14 +269,19 @@ __global__ void k_bitmap_from_edges(int64_t n, int64_t wpr, int64_t m, const int
     atomicOr(&bits[j * wpr + (i >> 5)], 1u << (i & 31));
 }
 
-// every rank's segment of the gathered edge lists -> symmetric bitmap: segment s = [ei (cap) | ej (cap) | count | pad]
+// every rank's segment of the gathered edge lists -> symmetric bitmap: segment s = [ei (cap) | ej (cap) | count | overflowed | pad].
+// A segment whose rank had more edges than `cap` arrives truncated WITH its rank's overflow word: every rank that rebuilds the
+// bitmap raises its own sticky flag then, so all ranks reject the sample together (one rank raising alone would leave the
+// others in the next collective).
 __global__ void k_bitmap_from_edge_segments(int64_t n, int64_t wpr, int nseg, int64_t cap, int64_t stride,
-                                            const int32_t* __restrict__ edges, uint32_t* __restrict__ bits) {
+                                            const int32_t* __restrict__ edges, uint32_t* __restrict__ bits,
+                                            int32_t* __restrict__ overflow) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= (int64_t)nseg * cap) return;
     const int64_t s = g / cap, e = g - s * cap;
     const int32_t* seg = edges + s * stride;
     int64_t cnt = seg[2 * cap];
+    if (e == 0 && overflow && (seg[2 * cap + 1] != 0 || cnt > cap || cnt < 0)) atomicOr(overflow, 1);
     if (cnt > cap) cnt = cap;
     if (e >= cnt) return;
     const int64_t i = seg[e], j = seg[cap + e];
@@ -401,11 +406,15 @@ extern "C" int gm_upper_edges_ranges(int64_t n, int64_t wpr, const uint32_t* upp
     }
     if (total == 0) {
         GM_HIP(hipMemsetAsync(count, 0, sizeof(int32_t), s));
+        GM_HIP(hipMemcpyAsync(count + 1, overflow, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
         return GM_OK;
     }
     hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, total, rowptr_ws, capacity, overflow);
     GM_LAUNCH_CHECK();
     GM_HIP(hipMemcpyAsync(count, rowptr_ws + total, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    // the (sticky) overflow word travels with the segment: the count above is clamped to the capacity, so without it the
+    // ranks that receive a truncated list could not tell
+    GM_HIP(hipMemcpyAsync(count + 1, overflow, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     int64_t off = 0;
     for (int r = 0; r < nranges; ++r) {
         const int64_t b = row_ranges[2 * r], e = row_ranges[2 * r + 1];
@@ -419,13 +428,13 @@ extern "C" int gm_upper_edges_ranges(int64_t n, int64_t wpr, const uint32_t* upp
 }
 
 extern "C" int gm_bitmap_from_edge_segments(int64_t n, int64_t wpr, int nseg, int64_t cap, int64_t stride,
-                                            const int32_t* edges, uint32_t* bits, gm_stream_t stream) {
+                                            const int32_t* edges, uint32_t* bits, int32_t* overflow, gm_stream_t stream) {
     if (int rc = check_bitmap_args(n, wpr)) return rc;
-    GM_REQUIRE(nseg > 0 && cap > 0 && stride > 2 * cap && edges && bits, "bad arguments");
+    GM_REQUIRE(nseg > 0 && cap > 0 && stride >= 2 * cap + 2 && edges && bits, "bad arguments");
     GM_REQUIRE((int64_t)nseg * cap < (1ll << 38), "edge buffer too large");
     GM_HIP(hipMemsetAsync(bits, 0, sizeof(uint32_t) * (size_t)(n * wpr), as_stream(stream)));
     hipLaunchKernelGGL(k_bitmap_from_edge_segments, dim3((unsigned)(((int64_t)nseg * cap + 255) / 256)), dim3(256), 0,
-                       as_stream(stream), n, wpr, nseg, cap, stride, edges, bits);
+                       as_stream(stream), n, wpr, nseg, cap, stride, edges, bits, overflow);
     GM_LAUNCH_CHECK();
     return GM_OK;
 }

@@ -132,15 +132,9 @@ k_linear(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t l
         for (int st = 0; st < KT / 4; ++st) {
             float av[TM], bv[TN];
 #pragma unroll
-#ifdef GM_GEMM_X_NOLDS   // exploration only (tools/build_gemm_variant.sh): results are garbage
-            for (int a = 0; a < TM; ++a) av[a] = (float)(lane + a + st);
-#pragma unroll
-            for (int b = 0; b < TN; ++b) bv[b] = (float)(lane - b - st);
-#else
             for (int a = 0; a < TM; ++a) av[a] = as[16 * a * LD + 4 * st];
 #pragma unroll
             for (int b = 0; b < TN; ++b) bv[b] = bs[16 * b * LD + 4 * st];
-#endif
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -154,21 +148,15 @@ k_linear(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t l
     const int64_t T = (K + KT - 1) / KT;                // all tiles (the last one may be ragged)
     // tile `it` lives in LDS buffer it&1; `cur` holds tile it+1 (in flight or landed), `nxt` receives tile it+2
     auto step_fast = [&](int64_t it, Regs& cur, Regs& nxt) {
-#ifndef GM_GEMM_X_NOLOAD
         fetch_fast(nxt, (it + 2) * KT);
-#endif
         __builtin_amdgcn_sched_barrier(0);              // loads above the MFMAs, their first use below them
-#ifndef GM_GEMM_X_NOSTASH
         // tile it+1 goes to LDS BEFORE this tile's MFMAs (its buffer was last read before the previous barrier): the wave
         // reaches the barrier straight out of its MFMA run instead of via a load wait and four LDS stores (+2% over the shapes)
         stash(cur, (int)((it + 1) & 1));
         __builtin_amdgcn_sched_barrier(0);
-#endif
         multiply((int)(it & 1));
         __builtin_amdgcn_sched_barrier(0);
-#ifndef GM_GEMM_X_NOBAR
         __syncthreads();
-#endif
     };
     auto step_any = [&](int64_t it, Regs& cur, Regs& nxt) {
         if (it + 2 < T) fetch_any(nxt, (it + 2) * KT);
@@ -297,22 +285,14 @@ static int launch_linear(int64_t M, int64_t N, int64_t K, const float* A, int64_
     return GM_OK;
 }
 
-#ifndef GM_GEMM_BIG_TILES
-#define GM_GEMM_BIG_TILES 400   // at least this many 128x128 tiles: the 128x128 / 8-wave configuration
-#endif
-
-#ifndef GM_GEMM_SMALL_TILES
-#define GM_GEMM_SMALL_TILES 384   // at most this many 64x64 tiles: the 32x64 configuration
-#endif
+constexpr int64_t GM_GEMM_BIG_TILES = 400;     // at least this many 128x128 tiles: the 128x128 / 8-wave configuration
+constexpr int64_t GM_GEMM_SMALL_TILES = 384;   // at most this many 64x64 tiles: the 32x64 configuration
 
 extern "C" int gm_linear(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw,
                          const float* bias, float* C, int64_t ldc, int relu, gm_stream_t stream) {
     GM_REQUIRE(M > 0 && N > 0 && K > 0 && A && W && C, "bad arguments");
     GM_REQUIRE(lda >= K && ldw >= K && ldc >= N, "leading dimension too small");
     hipStream_t s = as_stream(stream);
-#ifdef GM_GEMM_CFG   // exploration builds (tools/build_gemm_variant.sh): one configuration for every shape
-    return launch_linear<GM_GEMM_CFG>(M, N, K, A, lda, W, ldw, bias, C, ldc, relu, s);
-#endif
     if (N <= 4 && M >= 65536 && K % SK_KC == 0 && K <= SK_MAXK && lda % 4 == 0 && aligned(A, 16) && (M + 255) / 256 < (1ll << 31)) {
         switch ((int)N) {      // the pair MLP's output layer on a training batch: see k_linear_skinny
             case 1: return launch_skinny<1>(M, K, A, lda, W, ldw, bias, C, ldc, relu, s);

@@ -26,14 +26,8 @@ namespace gm {
 // is fetched across the L2 boundary about once instead of once per XCD.  With r < 8 slabs in a (last) round, XCD x takes slab
 // x % r and the rows are dealt over the XCDs that share a slab.  A wrong guess about placement costs speed only.
 constexpr int SP_SEG = 64;          // neighbours per segment (oracle: GMO_SPMM_SEG)
-#ifndef GM_SPMM_RB                  // exploration builds (tools/spmm_ab.py) may override the two sizes below
-#define GM_SPMM_RB 32
-#endif
-#ifndef GM_SPMM_PARTS
-#define GM_SPMM_PARTS 96
-#endif
-constexpr int SP_RB = GM_SPMM_RB;   // rows per workgroup (<= 64: wave 0 lists them, a lane per row)
-constexpr int SP_PARTS = GM_SPMM_PARTS;        // segment sums a workgroup can hold in LDS for its multi-segment rows (128-byte slabs)
+constexpr int SP_RB = 32;           // rows per workgroup (<= 64: wave 0 lists them, a lane per row)
+constexpr int SP_PARTS = 96;        // segment sums a workgroup can hold in LDS for its multi-segment rows (128-byte slabs)
 constexpr int SP_PARTS_WIDE = 16;   // ... with 2 KB slabs (each sum is 16x larger)
 constexpr int SP_SERIAL = 0xFFFF;   // item that walks all segments of its row itself (LDS slots exhausted)
 
@@ -208,9 +202,6 @@ k_spmm_seg(int64_t n, const int32_t* __restrict__ rowptr, const int32_t* __restr
                 for (int q = 0; q < NB; ++q) {
                     const bool in = k + q < cnt;
                     int j = in ? idx_s[ib + k + q] : 0;
-#ifdef GM_SPMM_X_SCRAMBLE   // exploration: same structure, gather targets spread uniformly (wrong results) -- isolates hot-row effects
-                    j = (int)(((uint32_t)j * 2654435761u) % (uint32_t)n);
-#endif
                     w[q] = TRANSPOSED ? (in ? w_s[ib + k + q] : 0.0f) : inv_row;
 #pragma unroll
                     for (int c = 0; c < CH; ++c)

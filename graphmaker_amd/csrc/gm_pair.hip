@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
     float* b1s = hJs + TILE * LDR;
     float* dws = b1s + HE;                         // W2[1] - W2[0]: the second layer is evaluated as a logit difference
     float* W2s = dws + HE;                         // both rows of W2 (read by the DBG instantiation only)
-    int* tile_s = reinterpret_cast<int*>(W2s + 2 * HE);   // tile_s[0..1]: ring of queue items, [2]: items published
+    int* tile_s = reinterpret_cast<int*>(W2s + 2 * HE);   // tile_s[0..1]: ring of queue items, [2]: items published, [3]: abort
     int* stg_s = tile_s + 4;                       // stg_s[w], w < 4: tiles wave w has staged
     int* turn_s = tile_s + 8;                      // turn_s[w]: MFMA row-units wave w has issued so far (hand-off flags)
     float* b1s2 = W2s + 2 * HE + 32;               // a second copy of b1: strip 1's accumulators are read from it directly
@@ -165,7 +165,8 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
     const float b20 = a.b2[0], b21 = a.b2[1];
     const float db = b21 - b20;
 
-    if (tid == 0) { tile_s[0] = (int)atomicAdd(a.counter, 1u); tile_s[2] = 0; }
+    // a launch that finds the stall word set (an earlier launch lost a hand-shake and the host has not dealt with it) does nothing
+    if (tid == 0) { tile_s[0] = stall_word_set(a.stall) ? QUEUE_END : (int)atomicAdd(a.counter, 1u); tile_s[2] = 0; tile_s[3] = 0; }
     if (tid < 8) tab_s[tid] = a.tab[((tid & 3) == 0 ? 0 : (tid & 3) == 1 ? 4 : (tid & 3) == 2 ? 2 : 6) + (tid >> 2)];
     if (tid < 8) turn_s[tid] = 0;
     if (tid < 4) stg_s[tid] = 0;
@@ -175,7 +176,7 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
     int64_t t = __builtin_amdgcn_readfirstlane(tile_s[0]);
     int seq = 0;                                   // queue items this workgroup has finished (same in every wave)
     int units_done = 0;                            // row-units this wave has multiplied (same count in every wave)
-    bool stalled = false;
+    lds_flag* abort_s = as_lds_flag(tile_s + 3);   // raised by the first wave of this workgroup whose wait gave up
     if (t < a.nitems) {                            // first item: staged by everybody, behind a barrier
         int64_t i0, j0, row_end, tile;
         int tj, ub, ue;
@@ -186,11 +187,6 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
     __syncthreads();
     lds_flag* my_turn = as_lds_flag(turn_s + wv);
     lds_flag* partner_turn = as_lds_flag(turn_s + (wv ^ 4));
-#ifdef GM_PAIR_STAMP   // diagnostic build: cycle sums of wave 0 / wave 4 of block 0 -> post_dbg (never in the product)
-    unsigned long long st_mma = 0, st_epi = 0, st_phase = 0, st_n = 0, st_init = 0, st_wait = 0;
-#define STAMP() __builtin_readcyclecounter()
-    const unsigned long long st_c0 = STAMP(), st_r0 = wall_clock64();   // shader cycles vs the constant 100 MHz clock
-#endif
 
     while (t < a.nitems) {
         int64_t i0, j0, row_end, tile;
@@ -199,16 +195,13 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
         decode_tile(a, tile, i0, j0, tj, row_end);
 
         // the h rows of item number `seq` are in LDS once waves 0-3 have all staged `seq` tiles
-        stalled |= !wait_all_ge(as_lds_flag(stg_s), 4, seq, lane);
+        if (!wait_all_ge(as_lds_flag(stg_s), 4, seq, lane, abort_s, a)) break;
 
         floatx16 acc[2][4];
         // 8 row-units per wave and tile.  The two waves of a SIMD (w, w+4) alternate on the matrix pipe: group 0 runs
         // unit u, then group 1 runs unit u while group 0 does the VALU epilogue of its unit, and so on.  The turn is
         // handed over through turn_s[] in LDS (no data passes between the waves, only the right to issue MFMAs).
         for (int u = ub; u < ue; ++u) {
-#ifdef GM_PAIR_STAMP
-            const unsigned long long ph0 = STAMP();
-#endif
             const int il = wv + 8 * u;
             const int64_t i = i0 + il;
             const bool active = i < row_end && i < a.n;      // wave-uniform
@@ -237,23 +230,13 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
                 prep_frag(f0);
             }
             __builtin_amdgcn_sched_barrier(0);
-#ifdef GM_PAIR_STAMP
-            st_init += STAMP() - ph0;
-            const unsigned long long wt0 = STAMP();
-#endif
             {   // wait for the partner: group 0 needs its partner's unit (units_done-1), group 1 its partner's unit units_done
-                const int need = units_done + grp;
-                // bounded: the order is a speed matter only, results never depend on it
-                for (int spin = 0; spin < (1 << 16) && *partner_turn < need; ++spin) __builtin_amdgcn_s_sleep(1);
+                // bounded, and giving up raises nothing: the order is a speed matter only, results never depend on it
+                LdsWait w{partner_turn, 1, units_done + grp, lane, abort_s, &a};
+                gm_pair_protocol::bounded_wait(w, gm_pair_protocol::TURN_SPINS, false);
             }
             __builtin_amdgcn_sched_barrier(0);
-#ifdef GM_PAIR_STAMP
-            st_wait += STAMP() - wt0;
-#endif
             if (active) {
-#ifdef GM_PAIR_STAMP
-                const unsigned long long m1 = STAMP();
-#endif
                 // the multiplying wave outranks its partner at the SIMD's issue arbiter (no priorities: 22.8 instead of 21.9 ms;
                 // epilogue wave high, or one group only: no difference -- DESIGN.md 4.1)
                 __builtin_amdgcn_s_setprio(1);
@@ -275,29 +258,16 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 __builtin_amdgcn_s_setprio(0);
-#ifdef GM_PAIR_STAMP
-                asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[1][3]));
-                st_mma += STAMP() - m1;
-                st_n += 1;
-#endif
             }
             __builtin_amdgcn_sched_barrier(0);
             ++units_done;
             if (lane == 0) *my_turn = units_done;
             __builtin_amdgcn_sched_barrier(0);
-#ifdef GM_PAIR_STAMP
-            const unsigned long long ep0 = STAMP();
-#endif
             if (active) {
                 EpiCtx ec;
                 ec.dws = dws; ec.W2s = W2s; ec.tab_s = tab_s; ec.rng_mine = rng_s + wv * 256; ec.db = db; ec.b20 = b20; ec.b21 = b21;
                 pair_epilogue<DBG>(a, ec, acc, i, i0, j0, tj, u, ub, wv, lane);
             }
-#ifdef GM_PAIR_STAMP
-            asm volatile("s_nop 0" ::: "memory");
-            st_epi += STAMP() - ep0;
-            st_phase += STAMP() - ph0;
-#endif
         }
         // ---- tile hand-over, no barrier.  Ordering rests on the LDS flags (LDS serves a wave's requests in order):
         //   * a wave publishes turn_s after the last fragment read of its unit was issued;
@@ -307,12 +277,13 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
         ++seq;
         if (wv == 0) {
             if (lane == 0) {
-                tile_s[seq & 1] = (int)atomicAdd(a.counter, 1u);   // slot last read before item seq-1 began
+                const int next = (int)atomicAdd(a.counter, 1u);
+                tile_s[seq & 1] = stall_word_set(a.stall) ? QUEUE_END : next;   // slot last read before item seq-1 began
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 *as_lds_flag(tile_s + 2) = seq;
             }
         }
-        stalled |= !wait_all_ge(as_lds_flag(tile_s + 2), 1, seq, lane);
+        if (!wait_all_ge(as_lds_flag(tile_s + 2), 1, seq, lane, abort_s, a)) break;
         t = __builtin_amdgcn_readfirstlane(as_lds_flag(tile_s)[seq & 1]);
         if (grp == 0 && t < a.nitems) {
             int64_t ni0, nj0, nre, ntile;
@@ -321,20 +292,12 @@ __global__ void __launch_bounds__(PAIR_THREADS, 2) k_pair_score_sample(const Pai
             decode_tile(a, ntile, ni0, nj0, ntj_, nre);
             float4 v[16];
             stage_load_half(a.h, a.n, ni0, nj0, tid, v);
-            stalled |= !wait_all_ge(as_lds_flag(turn_s), 8, units_done, lane);
+            if (!wait_all_ge(as_lds_flag(turn_s), 8, units_done, lane, abort_s, a)) break;
             stage_store_half(hIs, hJs, tid, v);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) *as_lds_flag(stg_s + wv) = seq;
         }
     }
-    if (stalled && lane == 0) atomicOr(a.stall, 1u);
-#ifdef GM_PAIR_STAMP
-    if (blockIdx.x == 0 && lane == 0 && (wv == 0 || wv == 4) && a.post_dbg) {
-        float* o = a.post_dbg + 8 * grp;
-        o[0] = (float)st_mma; o[1] = (float)st_epi; o[2] = (float)st_phase; o[3] = (float)st_n; o[4] = (float)st_init;
-        o[5] = (float)(STAMP() - st_c0); o[6] = (float)(wall_clock64() - st_r0); o[7] = (float)st_wait;
-    }
-#endif
 }
 
 }  // namespace gm
@@ -356,11 +319,7 @@ extern "C" int gm_pair_score_sample_ranges(int64_t n, int64_t hE, const float* h
         return rc;
     if (grid == 0) return GM_OK;
     hipStream_t s = as_stream(stream);
-#ifdef GM_PAIR_STAMP   // the diagnostic build passes its stamp buffer as post_dbg and must time the product instantiation
-    const bool dbg = logits_dbg != nullptr;
-#else
     const bool dbg = logits_dbg || post_dbg || u;
-#endif
     if (dbg) hipLaunchKernelGGL(k_pair_score_sample<true>, dim3(grid), dim3(PAIR_THREADS), 0, s, a);
     else hipLaunchKernelGGL(k_pair_score_sample<false>, dim3(grid), dim3(PAIR_THREADS), 0, s, a);
     GM_LAUNCH_CHECK();

@@ -2,6 +2,7 @@
 // arguments, the tile queue decoding, the bounded LDS flag wait, and the host-side argument check / queue set-up.
 #pragma once
 #include "gm_common.h"
+#include "gm_pair_protocol.h"
 
 namespace gm {
 
@@ -35,7 +36,8 @@ struct PairArgs {
     float* logits_dbg;
     float* post_dbg;
     uint32_t* counter;
-    uint32_t* stall;                // set (never cleared) when an LDS hand-shake below timed out: results are then void
+    uint32_t* stall;                // set (cleared by the host only) when an LDS hand-shake timed out: results are then void, and
+                                    // a launch that finds it set does nothing (gm_pair_protocol.h)
     int ntj;
     int64_t ntiles;
     // work items of the shared queue: items [0, nfull) are whole 64x64 tiles; the remaining tiles (fewer than one per
@@ -82,19 +84,39 @@ __device__ __forceinline__ void decode_item(const PairArgs& a, int64_t it, int64
 typedef __attribute__((address_space(3))) volatile int lds_flag;
 __device__ __forceinline__ lds_flag* as_lds_flag(int* p) { return (lds_flag*)p; }
 
-// Wait until the first `cnt` ints at `flags` are all >= need (every lane returns the same answer).  These waits guard
-// LDS contents, so they are long; a wave that gives up reports it through PairArgs::stall instead of hanging the GPU.
-__device__ __forceinline__ bool wait_all_ge(lds_flag* flags, int cnt, int need, int lane) {
-    for (int spin = 0; spin < (1 << 22); ++spin) {
+// The bounded hand-shake (gm_pair_protocol.h) over LDS flags.  satisfied(): the first `cnt` ints at `flags` are all >= need
+// (every lane returns the same answer).  A wait that gives up raises the workgroup's abort word and the launch's sticky stall
+// word; after that no wave of the workgroup waits again and every wave leaves the tile loop at its next check, so a lost
+// hand-shake costs one timeout (~30 ms), not one per remaining wait (minutes), and the host learns of it from the stall word.
+struct LdsWait {
+    lds_flag* flags;
+    int cnt, need, lane;
+    lds_flag* abort;
+    const PairArgs* args;          // the stall word's address is fetched (kernel arguments) only if a wait gives up
+    __device__ __forceinline__ bool satisfied() const {
         const int v = lane < cnt ? flags[lane] : 0x7fffffff;
         if (__all(v >= need)) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // later LDS reads stay below the flag read
             return true;
         }
-        __builtin_amdgcn_s_sleep(1);
+        return false;
     }
-    return false;
+    __device__ __forceinline__ bool aborted() const { return *abort != 0; }
+    __device__ __forceinline__ void raise() const {
+        if (lane == 0) { *abort = 1; atomicOr(args->stall, 1u); }
+    }
+    __device__ __forceinline__ void pause() const { __builtin_amdgcn_s_sleep(1); }
+};
+__device__ __forceinline__ bool wait_all_ge(lds_flag* flags, int cnt, int need, int lane, lds_flag* abort, const PairArgs& a) {
+    LdsWait w{flags, cnt, need, lane, abort, &a};
+    return gm_pair_protocol::bounded_wait(w, gm_pair_protocol::WAIT_SPINS, true);
 }
+// has any launch that used this workspace reported a stall (and nobody cleared it since)?  Read past the caches: the word
+// is written by other workgroups of this launch
+__device__ __forceinline__ bool stall_word_set(const uint32_t* stall) {
+    return __hip_atomic_load(stall, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+}
+constexpr int QUEUE_END = 0x7fffffff;   // a queue item no launch has: "stop" (host check: nitems < QUEUE_END)
 
 __device__ __forceinline__ float relu_bits(float x) {   // max(x, 0) for non-NaN x, one integer max
     return __int_as_float(max(__float_as_int(x), 0));
@@ -217,12 +239,10 @@ __device__ __forceinline__ void pair_epilogue(const PairArgs& a, const EpiCtx& c
     const bool bit = valid && draw2(u, p0, p1);
     const unsigned long long m = __ballot(bit);
     if (lane == 0) *reinterpret_cast<unsigned long long*>(a.out_upper + i * a.wpr + 2 * (int64_t)tj) = m;
-#ifndef GM_PAIR_STAMP   // the diagnostic build reuses post_dbg for its stamps
     if (DBG && valid) {
         if (a.logits_dbg) { a.logits_dbg[2 * rank] = L0; a.logits_dbg[2 * rank + 1] = L1; }
         if (a.post_dbg) { a.post_dbg[2 * rank] = p0; a.post_dbg[2 * rank + 1] = p1; }
     }
-#endif
 }
 
 }  // namespace gm
@@ -276,7 +296,7 @@ static inline int gm_build_pair_args(int64_t n, int64_t hE, const float* h, cons
     if (a.nranges == 0) return GM_OK;
     for (int q = a.nranges; q < MAXR; ++q) a.tile_base[q + 1] = a.tile_base[a.nranges];
     a.ntiles = a.tile_base[a.nranges];
-    GM_REQUIRE(a.ntiles > 0 && a.ntiles < (1ll << 31), "tile count out of range");
+    GM_REQUIRE(a.ntiles > 0 && a.ntiles < (1ll << 31) - 8 * 4096, "tile count out of range");   // nitems < QUEUE_END
     int dev = 0, cus = 0;
     GM_HIP(hipGetDevice(&dev));
     GM_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));

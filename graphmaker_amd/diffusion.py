@@ -128,6 +128,9 @@ class BaseModel(nn.Module):
         # "f32" (exact, default) | "bf16x3" | "bf16": opt-in matrix-core precision of the pair MLP's hidden layer (ops.py)
         self.pair_precision = "f32"
         self._prof = None          # None, or dict phase -> [(start_event, end_event)] (bench.py / profiling)
+        # edges per rank an exchange segment of the multi-GPU step holds; None: parallel.edge_segment_capacity (4x the edge
+        # marginal's share).  The same value on every rank.
+        self.edge_segment_capacity = None
 
     class _Phase:
         """Brackets a phase of the step with events on torch's current stream (the stream every library call is
@@ -166,7 +169,7 @@ class BaseModel(nn.Module):
         """The sampled edges of this rank's pair chunks -> compact sorted list -> one all-gather -> the symmetric bitmap of
         E_s on every rank (model/diffusion.py:421-424 across ranks; parallel.py)."""
         n, dev = self.num_nodes, upper.device
-        cap = parallel.edge_segment_capacity(plan, self.transition.E_marginal_host[1])
+        cap = self.edge_segment_capacity or parallel.edge_segment_capacity(plan, self.transition.E_marginal_host[1])
         seg = self._buf("edge_seg", (2 * cap + parallel.SEG_HEADER,), torch.int32, dev, zero=True)
         recv = self._buf("edge_recv", (plan.world, 2 * cap + parallel.SEG_HEADER), torch.int32, dev, zero=True)
         rowptr_ws = self._buf("edge_rowptr", (2 * plan.chunk_rows + 1,), torch.int32, dev)
@@ -176,7 +179,7 @@ class BaseModel(nn.Module):
         with self.phase("allgather_E"):
             parallel.gather_edge_segments(plan, seg, recv, group)
         with self.phase("symmetrize"):
-            return ops.bitmap_from_edge_segments(n, recv, cap)
+            return ops.bitmap_from_edge_segments(n, recv, cap, overflow=ovf)     # any rank's overflow reaches every rank
 
     def _const(self, key, host_array, device):
         """Small per-step constants (time embedding input, posterior tables) uploaded once per (key, device) instead of
@@ -385,8 +388,9 @@ class BaseModel(nn.Module):
             if key[0] == "edge_overflow" and int(buf.item()):
                 buf.zero_()
                 raise RuntimeError("a rank sampled more edges than its exchange segment holds (parallel.edge_segment_capacity: "
-                                   "4x the edge marginal's share): the sample is invalid; the model's E_marginal does not "
-                                   "describe the graphs it generates")
+                                   "4x the edge marginal's share; every rank raises this together): the sample is invalid; the "
+                                   "model's E_marginal does not describe the graphs it generates -- set "
+                                   "model.edge_segment_capacity on every rank")
         X = torch.transpose(x_onehot.reshape(n, Fa, -1), 0, 1)             # model/diffusion.py:899-901
         Y_one_hot = F.one_hot(Y32.long(), num_classes=self.num_classes_Y).float()
         if dense:

@@ -141,8 +141,9 @@ def adjacency_from_bitmap(bits, n, workspace=None, rows=None):
 
 
 def upper_edges_of_rows(upper, n, row_ranges, segment, cap, rowptr_ws, overflow):
-    """gm_upper_edges_ranges into a segment [ei (cap) | ej (cap) | count | pad] (int32, 2*cap + 16 entries): the sampled
-    edges (i<j) of `row_ranges` of the upper-triangle bitmap, sorted; count and an overflow flag stay on the device."""
+    """gm_upper_edges_ranges into a segment [ei (cap) | ej (cap) | count | overflowed | pad] (int32, 2*cap + 16 entries): the
+    sampled edges (i<j) of `row_ranges` of the upper-triangle bitmap, sorted; count and the overflow flag stay on the device
+    (and travel inside the segment)."""
     require(upper, torch.int32, "upper")
     require(segment, torch.int32, "segment")
     flat = [int(v) for be in row_ranges for v in be]
@@ -152,13 +153,14 @@ def upper_edges_of_rows(upper, n, row_ranges, segment, cap, rowptr_ws, overflow)
     return segment
 
 
-def bitmap_from_edge_segments(n, segments, cap, out=None):
-    """The symmetric bitmap of the edges held in `segments` (nseg, 2*cap + 16) int32 (upper_edges_of_rows layout)."""
+def bitmap_from_edge_segments(n, segments, cap, out=None, overflow=None):
+    """The symmetric bitmap of the edges held in `segments` (nseg, 2*cap + 16) int32 (upper_edges_of_rows layout).
+    overflow: this rank's sticky (1,) int32 flag; set when ANY gathered segment was truncated on its rank."""
     require(segments, torch.int32, "segments")
     wpr = words_per_row(n)
     bits = out if out is not None else torch.empty((n, wpr), dtype=torch.int32, device=segments.device)
     L.call("gm_bitmap_from_edge_segments", I64(n), I64(wpr), I32(segments.shape[0]), I64(cap), I64(segments.shape[1]),
-           ptr(segments), ptr(bits), stream_ptr())
+           ptr(segments), ptr(bits), ptr(overflow), stream_ptr())
     return bits
 
 
@@ -298,7 +300,9 @@ def pair_workspace(device):
 
 def check_pair_workspace(workspace):
     """Host read (synchronises): raise if a pair kernel that used this workspace reported a timed-out hand-shake."""
-    if int(workspace[64:68].view(torch.int32).item()) != 0:
+    word = workspace[64:68].view(torch.int32)
+    if int(word.item()) != 0:
+        word.zero_()          # a launch that finds the word set does nothing: clear it so the workspace can be used again
         raise RuntimeError("gm_pair_score_sample: a wave timed out waiting for an LDS hand-shake; the sampled "
                            "adjacency of this trajectory is void (see include/graphmaker_hip.h)")
 

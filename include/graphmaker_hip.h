@@ -81,18 +81,22 @@ int gm_bitmap_from_upper_edges(int64_t n, int64_t wpr, int64_t m, const int32_t*
 /* Multi-GPU exchange of the sampled edges ("the sampled edge lists are gathered back": E_t[dst,src] = E_t[src,dst] = draw,
  * model/diffusion.py:421-424, done across ranks).
  * gm_upper_edges_ranges: the edges (i<j) of up to 4 row ranges (HOST array [b0,e0,b1,e1,...], a rank's pair chunks) of the
- *   upper-triangle bitmap the pair kernel wrote, as a compact list sorted by (i, j): ei[k], ej[k] for k < *count (device
+ *   upper-triangle bitmap the pair kernel wrote, as a compact list sorted by (i, j): ei[k], ej[k] for k < count[0] (device
  *   int32, clamped to `capacity`); rowptr_ws: scratch of R+1 entries, R = total number of rows in the ranges.  At most
- *   `capacity` edges are written; *overflow (device, sticky) is OR-ed with 1 when there were more.  The rows of `upper` must
+ *   `capacity` edges are written; *overflow (device, sticky) is OR-ed with 1 when there were more, and count[1] receives a
+ *   copy of *overflow, so that the word travels with the segment (`count` points at TWO int32).  The rows of `upper` must
  *   hold zeros in the words the pair kernel does not write (allocate it zeroed once; the kernel rewrites its words on every
  *   call).
  * gm_bitmap_from_edge_segments: the symmetric bitmap of E_s from every rank's list after ONE equal-sized all-gather of
- *   segments [ei (cap) | ej (cap) | count | padding] of `stride` int32 each (stride > 2*cap). */
+ *   segments [ei (cap) | ej (cap) | count | overflowed | padding] of `stride` int32 each (stride >= 2*cap + 2).  A
+ *   segment that arrives with its overflow word set (its rank sampled more edges than `cap`; the list is truncated) sets
+ *   *overflow (device, sticky, may be NULL) on THIS rank too: every rank then rejects the sample, not only the one that
+ *   overflowed. */
 int gm_upper_edges_ranges(int64_t n, int64_t wpr, const uint32_t* upper, int nranges, const int64_t* row_ranges,
                           int64_t capacity, int32_t* rowptr_ws, int32_t* ei, int32_t* ej, int32_t* count, int32_t* overflow,
                           gm_stream_t stream);
 int gm_bitmap_from_edge_segments(int64_t n, int64_t wpr, int nseg, int64_t cap, int64_t stride, const int32_t* edges,
-                                 uint32_t* bits, gm_stream_t stream);
+                                 uint32_t* bits, int32_t* overflow, gm_stream_t stream);
 
 /* ---- message passing: A @ H with A = D^-1 A (model/gnn.py:60-61, model/diffusion.py:255-256) ---- */
 int gm_spmm_mean(int64_t n, const int32_t* rowptr, const int32_t* colidx, const float* H, int64_t ldh, int64_t d,
@@ -173,9 +177,11 @@ int gm_hadamard_gather(int64_t B, int64_t d, const int64_t* src, const int64_t* 
  * 8-byte aligned with wpr a multiple of 4 (rows then stay aligned).  tab: HOST pointer to 8 floats tab[(i*2+k)*2+e] = Q_t[k][e]*Qbar_s[i][k]/Qbar_t[i][e].
  * workspace: >= 256 bytes, zeroed by the caller when it is allocated.  Word 0 is the tile counter (cleared by every
  * call).  Word 16 is a sticky trouble flag: the kernel's waves hand tiles to each other through flags in LDS without
- * workgroup barriers, and a wave that waits for such a flag far beyond any legitimate delay sets the word and carries
- * on, so that the GPU is never hung; the outputs of that call are then void.  The library never clears it: test it
- * wherever the caller synchronises anyway (graphmaker_amd does so once per trajectory).
+ * workgroup barriers (gm_pair_protocol.h).  A wave that waits for such a flag far beyond any legitimate delay (2^18 polls,
+ * ~30 ms) sets the word; from then on no wave of its workgroup waits again, every workgroup stops taking tiles, and the
+ * launch ends: the GPU is never hung, and the outputs of that call are void.  A launch that finds the word set does
+ * nothing (it ends at once, outputs untouched).  The library never clears it: test it wherever the caller synchronises
+ * anyway, and clear it before the workspace is used again (graphmaker_amd does both once per trajectory).
  * logits_dbg/post_dbg: optional (P,2) arrays indexed by rank. */
 int gm_pair_score_sample(int64_t n, int64_t hE, const float* h, const float* W1, const float* b1, const float* W2,
                          const float* b2, const uint32_t* bits_t, int64_t wpr, const float* tab,

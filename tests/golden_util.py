@@ -56,6 +56,18 @@ LARGE_CASES = {
                       gnn_X=dict(hidden_t=32, hidden_X=512, hidden_Y=64, num_gnn_layers=2, dropout=0.0),
                       gnn_E=dict(hidden_t=32, hidden_X=512, hidden_Y=64, hidden_E=128, num_gnn_layers=2,
                                  dropout=0.0)),
+    # BASELINE.json configs[1]: Cora shape with configs/cora/train_Async.yaml hyper-parameters (T_X=6, T_E=9)
+    "cora_async": dict(variant="Async", N=2708, F=1433, C=7, T_X=6, T_E=9, density=1.44e-3, seed=22, x_p1=(0.002, 0.02),
+                       edge_bias=3.0, attr_bias=2.0,
+                       mlp_X=dict(hidden_t=32, hidden_X=512, hidden_Y=64, num_mlp_layers=2, dropout=0.0),
+                       gnn_E=dict(hidden_t=32, hidden_X=512, hidden_Y=64, hidden_E=128, num_gnn_layers=2,
+                                  dropout=0.0)),
+    # BASELINE.json configs[2]: amazon_photo shape with configs/amazon_photo/train_Sync.yaml hyper-parameters
+    "photo_sync": dict(variant="Sync", N=7650, F=745, C=8, T=3, density=4.07e-3, seed=23, x_p1=(0.002, 0.02),
+                       edge_bias=3.0, attr_bias=2.0,
+                       gnn_X=dict(hidden_t=16, hidden_X=512, hidden_Y=64, num_gnn_layers=2, dropout=0.0),
+                       gnn_E=dict(hidden_t=16, hidden_X=512, hidden_Y=64, hidden_E=128, num_gnn_layers=2,
+                                  dropout=0.0)),
 }
 
 

@@ -615,6 +615,42 @@ def test_pair_kernel_large_against_oracle_rows_and_sharding(dev):
     assert torch.equal(dense, dense.T) and int(dense.diagonal().sum()) == 0
 
 
+def test_pair_kernel_planted_stall_word_ends_the_launch_at_once_and_is_reported(dev):
+    """The failure mode of a lost LDS hand-shake (gm_pair_protocol.h): the sticky stall word makes a launch end at once
+    instead of timing out wait after wait (r2: minutes of a busy GPU).  Planted here: a full-size launch (22 ms of work) with
+    the word already set must return in a few ms with its output untouched, the host check must raise AND clear the word,
+    and the next launch on the same workspace must give the clean result."""
+    ops = _ops()
+    n = 13752
+    g = torch.Generator(device="cpu").manual_seed(4)
+    h = (torch.randn(n, 128, generator=g) * 0.4).to(dev)
+    W1 = (torch.randn(128, 128, generator=g) / 11).to(dev)
+    b1 = (torch.randn(128, generator=g) * 0.1).to(dev)
+    W2 = (torch.randn(2, 128, generator=g) / 11).to(dev)
+    b2 = torch.tensor([3.0, -3.0], device=dev)
+    Em = np.array([1 - 2.6e-3, 2.6e-3], np.float32)
+    bits = ops.prior_E(n, float(Em[0]), float(Em[1]), dev, seed=3)
+    tab = orc.posterior_table_E(Em, 0.58304191, 0.84701216, 0.49384356)
+    ws = ops.pair_workspace(dev)
+    clean = ops.pair_score_sample(h, W1, b1, W2, b2, bits, tab, seed=9, step=2, workspace=ws).clone()
+    ops.check_pair_workspace(ws)
+    assert int(clean.ne(0).sum()) > 0
+    ws[64:68].view(torch.int32).fill_(1)                       # the planted stall word
+    out = torch.full_like(clean, 0x5A5A5A5A)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ops.pair_score_sample(h, W1, b1, W2, b2, bits, tab, seed=9, step=2, workspace=ws, out_upper=out)
+    e1.record()
+    torch.cuda.synchronize()
+    assert e0.elapsed_time(e1) < 5.0, f"a launch that found the stall word set took {e0.elapsed_time(e1):.2f} ms"
+    assert bool((out == 0x5A5A5A5A).all()), "the launch wrote output although the stall word was set"
+    with pytest.raises(RuntimeError, match="hand-shake"):
+        ops.check_pair_workspace(ws)
+    ops.check_pair_workspace(ws)                               # reported once, cleared with the report
+    again = ops.pair_score_sample(h, W1, b1, W2, b2, bits, tab, seed=9, step=2, workspace=ws)
+    assert torch.equal(again, clean)
+
+
 @pytest.mark.parametrize("hE,n", [(32, 333), (96, 130), (200, 257), (4, 64), (384, 70)])
 def test_pair_kernel_other_hidden_E(dev, hE, n):
     """hidden_E != 128 (model/gnn.py:204-231 takes any width; the shipped configurations use 128): the vector kernel of
@@ -684,10 +720,17 @@ def test_edge_list_exchange_kernels(dev, n, density):
     if len(ei) > 8:                                                     # a segment that is too small
         small = torch.full((2 * 4 + SEG_HEADER + 8,), -7, dtype=torch.int32, device=dev)
         ops.upper_edges_of_rows(upper, n, [(0, n)], small, 4, torch.empty(n + 1, dtype=torch.int32, device=dev), ovf)
-        assert int(ovf) == 1 and int(small[8]) == 4
+        assert int(ovf) == 1 and int(small[8]) == 4 and int(small[9]) == 1      # [count (clamped) | overflowed]
         np.testing.assert_array_equal(small[:4].cpu().numpy(), ei[:4])
         np.testing.assert_array_equal(small[4:8].cpu().numpy(), ej[:4])
-        assert bool((small[9:] == -7).all())
+        assert bool((small[10:] == -7).all())
+        # the truncated segment tells EVERY rank that rebuilds the bitmap from it (its own count is clamped and would not)
+        theirs = torch.zeros(1, dtype=torch.int32, device=dev)
+        two = torch.zeros((2, 2 * 4 + SEG_HEADER), dtype=torch.int32, device=dev)
+        two[1] = small[:2 * 4 + SEG_HEADER]
+        ops.bitmap_from_edge_segments(n, two, 4, overflow=theirs)
+        assert int(theirs) == 1
+        ovf.zero_()
     # partial-row adjacency (what a rank builds for its node block)
     b = bits_t(sym_bits, dev)
     full = ops.adjacency_from_bitmap(b, n)
@@ -1129,20 +1172,26 @@ def test_cora_size_whole_sample_bit_identical_to_oracle(dev, variant):
     assert 0 < len(ei) < n * 200, "degenerate graph: the comparison would be vacuous"
 
 
-def test_cora_size_steps_and_sample_against_the_reference(dev):
-    """BASELINE.json configs[0]/[1] shape: the reference's own ModelSync.sample() at N=2708, F=1433 with the hidden sizes of
-    configs/cora/train_Sync.yaml (fixture cora_sync, generated by tools/gen_golden.py from /root/reference).  Every reverse
-    step is teacher-forced from the reference's input state; a draw may differ from the reference only within KNIFE of its
-    threshold (counted, none expected); then the free-running sample() must end in the reference's final graph."""
+@pytest.mark.parametrize("name", ["cora_sync", "cora_async", "photo_sync"])
+def test_baseline_size_steps_and_sample_against_the_reference(dev, name):
+    """BASELINE.json configs[0], [1], [2]: the reference's own ModelSync.sample() / ModelAsync.sample() at N=2708, F=1433
+    (configs/cora/train_{Sync,Async}.yaml hidden sizes and step counts) and N=7650, F=745 (configs/amazon_photo/train_Sync.yaml)
+    -- fixtures generated by tools/gen_golden.py from /root/reference.  Every reverse step is teacher-forced from the
+    reference's input state; a draw may differ from the reference only within KNIFE of its threshold (counted, none
+    expected); then the free-running sample() must end in the reference's final graph."""
     import graphmaker_amd as gm
     ops = _ops()
-    cfg = gu.LARGE_CASES["cora_sync"]
-    g = gu.load_golden("cora_sync")
-    N, F, T, seed = cfg["N"], cfg["F"], cfg["T"], cfg["seed"]
+    cfg = gu.LARGE_CASES[name]
+    g = gu.load_golden(name)
+    N, F, seed = cfg["N"], cfg["F"], cfg["seed"]
+    sync = cfg["variant"] == "Sync"
+    T_E = cfg["T"] if sync else cfg["T_E"]
+    T_X = cfg["T"] if sync else cfg["T_X"]
     Xm, Ym, Em = gu.marginals(cfg)
     sdX, sdE = gu.make_checkpoint(cfg)
-    model = gm.ModelSync(T=T, X_marginal=t_(Xm, dev), Y_marginal=t_(Ym, dev), E_marginal=t_(Em, dev),
-                         gnn_X_config=cfg["gnn_X"], gnn_E_config=cfg["gnn_E"], num_nodes=N)
+    kw = dict(X_marginal=t_(Xm, dev), Y_marginal=t_(Ym, dev), E_marginal=t_(Em, dev), gnn_E_config=cfg["gnn_E"], num_nodes=N)
+    model = gm.ModelSync(T=cfg["T"], gnn_X_config=cfg["gnn_X"], **kw) if sync else \
+        gm.ModelAsync(T_X=T_X, T_E=T_E, mlp_X_config=cfg["mlp_X"], **kw)
     model.graph_encoder.pred_X.load_state_dict({k: torch.from_numpy(v) for k, v in sdX.items()})
     model.graph_encoder.pred_E.load_state_dict({k: torch.from_numpy(v) for k, v in sdE.items()})
     model = model.to(dev).eval()
@@ -1150,36 +1199,57 @@ def test_cora_size_steps_and_sample_against_the_reference(dev):
     iu, ju = np.triu_indices(N, 1)
     W1, b1, W2, b2 = model.graph_encoder.pred_E.pair_params()
     flips = 0
-    for t in range(T, 0, -1):
-        bits_in = bits_t(gu.large_bits(N, g[f"e{t}_E_in_upper_nz"], g[f"e{t}_E_in_diag"]), dev)
-        x_in = t_(gu.large_x(g[f"e{t}_X_in_bits"], F), dev)
-        oh_in = ops.onehot_from_x(x_in)
-        x_s, _, bits_s = model.denoise_step(t, x_in, oh_in, Y32, bits_in, seed)
+
+    def check_edges(t, bits_in, oh_in, bits_s):
         want = gu.large_bits(N, g[f"e{t}_E_out_upper_nz"])
         got = bits_np(bits_s)
-        if not np.array_equal(got, want):
-            bad = np.flatnonzero(gu.upper_bit(got, iu, ju) != gu.upper_bit(want, iu, ju))
-            tab_E, _ = model.step_tables(t)
-            t_float = torch.tensor([t / T], dtype=torch.float32, device=dev)
-            h = model.graph_encoder.pred_E.gnn_encoder(t_float, oh_in, Y32, ops.adjacency_from_bitmap(bits_in, N))
-            _, _, po = ops.pair_score_sample(h, W1, b1, W2, b2, bits_in, tab_E, seed=seed, step=t, want_debug=True)
-            po = po.cpu().numpy()[bad]
-            u = orc.uniform_E(seed, t, N)[bad]
-            far = np.abs(u * (po[:, 0] + po[:, 1]) - po[:, 1]) > KNIFE
-            assert not far.any(), f"t={t}: {int(far.sum())} edge draws differ away from their threshold"
-            flips += len(bad)
-        x_ref = gu.large_x(g[f"x{t}_X_out_bits"], F)
-        v, f = np.nonzero(x_s.cpu().numpy() != x_ref)
-        if len(v):
-            _, tab_X = model.step_tables(t)
-            t_float = torch.tensor([t / T], dtype=torch.float32, device=dev)
-            diff = model.graph_encoder.pred_X._run(t_float, oh_in, Y32, ops.adjacency_from_bitmap(bits_in, N), diff_head=True)
-            _, _, pX = ops.attr_posterior_sample(diff, x_in, t_(tab_X, dev), seed=seed, step=t, want_debug=True, diff=True)
-            pX = pX.cpu().numpy()[v, f]
-            u = orc.uniform_X(seed, t, N, F)[f * N + v]
-            far = np.abs(u * (pX[:, 0] + pX[:, 1]) - pX[:, 1]) > KNIFE
-            assert not far.any(), f"t={t}: {int(far.sum())} attribute draws differ away from their threshold"
-            flips += len(v)
+        if np.array_equal(got, want):
+            return 0
+        bad = np.flatnonzero(gu.upper_bit(got, iu, ju) != gu.upper_bit(want, iu, ju))
+        tab_E = model.step_tables(t)[0] if sync else model.table_E(t)
+        t_float = torch.tensor([t / T_E], dtype=torch.float32, device=dev)
+        h = model.graph_encoder.pred_E.gnn_encoder(t_float, oh_in, Y32, ops.adjacency_from_bitmap(bits_in, N))
+        _, _, po = ops.pair_score_sample(h, W1, b1, W2, b2, bits_in, tab_E, seed=seed, step=t, want_debug=True)
+        po = po[torch.from_numpy(bad).to(dev)].cpu().numpy()
+        u = orc.uniform_E(seed, t, N)[bad]
+        far = np.abs(u * (po[:, 0] + po[:, 1]) - po[:, 1]) > KNIFE
+        assert not far.any(), f"t={t}: {int(far.sum())} edge draws differ away from their threshold"
+        return len(bad)
+
+    def check_attrs(t, x_in, oh_in, bits_in, x_s):
+        v, f = np.nonzero(x_s.cpu().numpy() != gu.large_x(g[f"x{t}_X_out_bits"], F))
+        if not len(v):
+            return 0
+        tab_X = model.step_tables(t)[1] if sync else model.table_X(t)
+        t_float = torch.tensor([t / T_X], dtype=torch.float32, device=dev)
+        A_t = ops.adjacency_from_bitmap(bits_in, N) if sync else None
+        diff = model.graph_encoder.pred_X._run(t_float, oh_in, Y32, A_t, diff_head=True)
+        _, _, pX = ops.attr_posterior_sample(diff, x_in, t_(tab_X, dev), seed=seed, step=t, want_debug=True, diff=True)
+        pX = pX.cpu().numpy()[v, f]
+        u = orc.uniform_X(seed, t, N, F)[f * N + v]
+        far = np.abs(u * (pX[:, 0] + pX[:, 1]) - pX[:, 1]) > KNIFE
+        assert not far.any(), f"t={t}: {int(far.sum())} attribute draws differ away from their threshold"
+        return len(v)
+
+    if sync:
+        for t in range(T_E, 0, -1):
+            bits_in = bits_t(gu.large_bits(N, g[f"e{t}_E_in_upper_nz"], g[f"e{t}_E_in_diag"]), dev)
+            x_in = t_(gu.large_x(g[f"e{t}_X_in_bits"], F), dev)
+            oh_in = ops.onehot_from_x(x_in)
+            x_s, _, bits_s = model.denoise_step(t, x_in, oh_in, Y32, bits_in, seed)
+            flips += check_edges(t, bits_in, oh_in, bits_s)
+            flips += check_attrs(t, x_in, oh_in, bits_in, x_s)
+    else:
+        for t in range(T_X, 0, -1):                                    # model/diffusion.py:1330-1358
+            x_in = t_(gu.large_x(g[f"x{t}_X_in_bits"], F), dev)
+            oh_in = ops.onehot_from_x(x_in)
+            x_s, _ = model.attribute_step(t, x_in, oh_in, Y32, seed)
+            flips += check_attrs(t, x_in, oh_in, None, x_s)
+        oh_final = ops.onehot_from_x(t_(gu.large_x(g["final_X_bits"], F), dev))
+        for t in range(T_E, 0, -1):                                    # :1379-1401, all steps on the final attributes
+            bits_in = bits_t(gu.large_bits(N, g[f"e{t}_E_in_upper_nz"], g[f"e{t}_E_in_diag"]), dev)
+            bits_s = model.structure_step(t, oh_final, Y32, bits_in, seed, reuse_X=t != T_E)
+            flips += check_edges(t, bits_in, oh_final, bits_s)
     assert flips == 0, f"{flips} threshold-level flips vs the reference (allowed by tolerance, not expected)"
     X, Y1h, el = model.sample(seed=seed, dense=False)
     np.testing.assert_array_equal(Y1h.argmax(1).cpu().numpy(), g["Y"])

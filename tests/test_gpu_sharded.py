@@ -98,6 +98,47 @@ def _worker_full(rank, world, port, backend, name, q):
         dist.destroy_process_group()
 
 
+def _worker_overflow(rank, world, port, backend, name, q):
+    """An exchange segment that is too small for ONE rank's edges: every rank must reject the sample (a rank that carried on
+    with a truncated graph would diverge from the others and hang the next collective)."""
+    import faulthandler
+    faulthandler.dump_traceback_later(45, exit=True)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        from graphmaker_amd import ops
+        from graphmaker_amd.parallel import ShardPlan
+        cfg, model = _model(name, dev)
+        n, T, seed = cfg["N"], cfg["T"], cfg["seed"]
+        Em = model.transition.E_marginal_host
+        Y32 = ops.prior_Y(n, model.Y_marginal, seed=seed)
+        bits = ops.prior_E(n, float(Em[0]), float(Em[1]), dev, seed=seed)
+        x, oh = ops.prior_X(n, model.X_marginal, seed=seed)
+        want = model.denoise_step(T, x, oh, Y32, bits, seed)
+        dense = ops.dense_from_bitmap(want[2], n).triu(1)
+        plans = [ShardPlan.make(n, world, r) for r in range(world)]
+        per_rank = [int(sum(dense[b:e].sum().item() for b, e in pl.pair_chunks())) for pl in plans]
+        assert min(per_rank) < max(per_rank), per_rank
+        model.edge_segment_capacity = (min(per_rank) + max(per_rank)) // 2        # only the fullest rank overflows
+        x_s, oh_s, bits_s = model.denoise_step(T, x, oh, Y32, bits, seed, plan=plans[rank])
+        torch.cuda.synchronize()
+        try:
+            model._finish(oh_s, Y32, bits_s, dense=False)
+            raised = False
+        except RuntimeError as e:
+            raised = "exchange segment" in str(e)
+        # the flag was cleared with the report: a roomy segment afterwards gives the single-GPU step again
+        model.edge_segment_capacity = None
+        model.__dict__["_bufs"] = {}
+        got = model.denoise_step(T, x, oh, Y32, bits, seed, plan=plans[rank])
+        model._finish(got[1], Y32, got[2], dense=False)
+        q.put((rank, raised, _same(want, got), max(per_rank)))
+    finally:
+        dist.destroy_process_group()
+
+
 def _run(world, backend, name, worker=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -117,7 +158,8 @@ def _run(world, backend, name, worker=None):
                 p.join(timeout=10)
     assert sorted(r[0] for r in res) == list(range(world))
     for rank, ok, ok2, edges in res:
-        assert ok and ok2, f"rank {rank} of {world} ({backend}, {name}): sharded sample differs from the single-GPU sample"
+        assert ok and ok2, f"rank {rank} of {world} ({backend}, {name}): sharded sample differs from the single-GPU sample" \
+            if worker is not _worker_overflow else f"rank {rank}: overflow raised={ok}, clean rerun equal={ok2}"
         assert edges > 0
 
 
@@ -129,6 +171,10 @@ def test_sharded_sample_ranks_share_one_gpu(world, name):
 @pytest.mark.parametrize("name", ["sync_mid", "async_mid"])
 def test_sharded_sample_one_rank_rccl(name):
     _run(1, "nccl", name)
+
+
+def test_edge_segment_overflow_on_one_rank_is_raised_by_every_rank():
+    _run(2, "gloo", "sync_mid", worker=_worker_overflow)
 
 
 def test_sharded_step_amazon_photo_size_two_ranks():

@@ -177,3 +177,17 @@ def test_committed_bench_line_follows_the_contract():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1 and r["traffic"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+
+
+def test_pair_kernel_handshake_protocol_is_bounded(tmp_path):
+    """The pair kernel's LDS hand-shake (graphmaker_amd/csrc/gm_pair_protocol.h), run on the host with threads for waves:
+    a clean run never gives up; ONE lost publication makes every wave leave the tile loop within
+    worst_case_polls_per_wave() unsatisfied polls and sets the sticky stall word; a launch that starts with the word set
+    does nothing (tests/host/pair_protocol_test.cpp)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "pair_protocol_test")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(root, "graphmaker_amd", "csrc"),
+                    os.path.join(root, "tests", "host", "pair_protocol_test.cpp"), "-o", exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr

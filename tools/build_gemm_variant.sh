@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/build_gemm_variant.sh <name> <extra hipcc flags...> -- exploration builds of the library that differ only in gm_gemm.hip
-# (e.g. -DGM_GEMM_NOLOAD); output graphmaker_amd/lib/libgm_<name>.so for tools/gemm_ab.py.  Never the product library.
+# (A/B builds of a modified source tree); output graphmaker_amd/lib/libgm_<name>.so for tools/gemm_ab.py.  Never the product library.
 set -e
 cd "$(dirname "$0")/../graphmaker_amd/csrc"
 name=$1; shift

@@ -14,7 +14,7 @@ path.  Two seams are filled in here, both recorded in DESIGN.md:
 Weights are synthetic (tests/golden_util.py); pre-trained checkpoints and datasets are remote fetches and
 unavailable offline.
 
-Usage:  python tools/gen_golden.py [case ...]
+Usage:  python tools/gen_golden.py [--timed-shim] [case ...]
 """
 import importlib.util
 import os
@@ -280,21 +280,29 @@ def _upper_nz(E):
     return torch.triu(E, diagonal=1).nonzero().numpy().astype(np.int32)
 
 
-def run_large_case(name, gnn, diffusion):
-    """A BASELINE.json-sized Sync case (gu.LARGE_CASES): the reference's own ModelSync.sample() (model/diffusion.py:797-905)
-    under the shared-RNG shim.  Stored: Y, the prior state, and per reverse step the sampled state going in and coming out
-    (upper edge lists, bit-packed attributes) -- what a teacher-forced step needs -- plus the final sample.  Then the same
-    model is sampled once more UNMODIFIED (torch.multinomial, no hooks) and timed: profiles/ref_cpu_<name>.json is the
-    reference's CPU path on this container's cores (SURVEY.md 8d "CPU baseline")."""
+def run_large_case(name, gnn, diffusion, timed="unmodified"):
+    """A BASELINE.json-sized case (gu.LARGE_CASES): the reference's own ModelSync.sample() (model/diffusion.py:797-905) or
+    ModelAsync.sample() (:1295-1410) under the shared-RNG shim.  Stored: Y, the prior state, and per reverse step the sampled
+    state going in and coming out (upper edge lists, bit-packed attributes) -- what a teacher-forced step needs -- plus the
+    final sample.  profiles/ref_cpu_<name>.json is the reference's CPU path on this container's cores (SURVEY.md 8d "CPU
+    baseline"): timed="unmodified" samples the same model once more WITHOUT shim or hooks (torch.multinomial) under a
+    stopwatch; timed="shim" reports the stopwatch of the fixture run itself (for the 25-minute amazon_photo case: the
+    shim replaces only the draw, < 1 % of a step, and the state capture sits outside get_E_t's stopwatch)."""
     import json
     import time
     cfg = gu.LARGE_CASES[name]
-    N, F, T = cfg["N"], cfg["F"], cfg["T"]
+    N, F = cfg["N"], cfg["F"]
+    sync = cfg["variant"] == "Sync"
+    T_E = cfg["T"] if sync else cfg["T_E"]
+    T_X = cfg["T"] if sync else cfg["T_X"]
     Xm, Ym, Em = gu.marginals(cfg)
     sdX, sdE = gu.make_checkpoint(cfg)
-    model = diffusion.ModelSync(T=T, X_marginal=torch.from_numpy(Xm), Y_marginal=torch.from_numpy(Ym),
-                                E_marginal=torch.from_numpy(Em), gnn_X_config=cfg["gnn_X"], gnn_E_config=cfg["gnn_E"],
-                                num_nodes=N)
+    kw = dict(X_marginal=torch.from_numpy(Xm), Y_marginal=torch.from_numpy(Ym), E_marginal=torch.from_numpy(Em),
+              gnn_E_config=cfg["gnn_E"], num_nodes=N)
+    if sync:
+        model = diffusion.ModelSync(T=cfg["T"], gnn_X_config=cfg["gnn_X"], **kw)
+    else:
+        model = diffusion.ModelAsync(T_X=T_X, T_E=T_E, mlp_X_config=cfg["mlp_X"], **kw)
     model.graph_encoder.pred_X.load_state_dict(to_t(sdX))
     model.graph_encoder.pred_E.load_state_dict(to_t(sdE))
     model.eval()
@@ -302,7 +310,7 @@ def run_large_case(name, gnn, diffusion):
     Ctx.seed, Ctx.N, Ctx.F = cfg["seed"], N, F
     Ctx.site, Ctx.e_step, Ctx.x_step = "Y", 0, 0
     orig = dict(sample_E=model.sample_E, sample_X=model.sample_X, sample_E_infer=model.sample_E_infer, get_E_t=model.get_E_t)
-    state = {"t": T + 1}
+    shim_step_s = []
 
     def pack_x(x_one_hot):     # (N,2F) float one-hot -> bit-packed (N, ceil(F/8)) of the class-1 indicator
         return np.packbits(x_one_hot.reshape(N, F, 2)[:, :, 1].numpy().astype(np.uint8), axis=1)
@@ -329,52 +337,77 @@ def run_large_case(name, gnn, diffusion):
         return r
 
     def get_E_t(device, loader, pred_E_func, t_float, X_t_one_hot, Y_0, E_t, *rest):
-        t = int(round(float(t_float.item()) * T))
-        Ctx.e_step = Ctx.x_step = t
+        t = int(round(float(t_float.item()) * T_E))
+        Ctx.e_step = t
+        if sync:
+            Ctx.x_step = t
         out[f"e{t}_E_in_upper_nz"] = _upper_nz(E_t)
         out[f"e{t}_E_in_diag"] = torch.diagonal(E_t).nonzero().reshape(-1).numpy().astype(np.int32)
-        out[f"e{t}_X_in_bits"] = pack_x(X_t_one_hot)
+        if sync:
+            out[f"e{t}_X_in_bits"] = pack_x(X_t_one_hot)
+        t0 = time.perf_counter()
         A_t, E_s = orig["get_E_t"](device, loader, pred_E_func, t_float, X_t_one_hot, Y_0, E_t, *rest)
+        shim_step_s.append(time.perf_counter() - t0)
         out[f"e{t}_E_out_upper_nz"] = _upper_nz(E_s)
+        print(f"  {name}: structure step t={t} {shim_step_s[-1]:.1f} s, {len(out[f'e{t}_E_out_upper_nz'])} edges", flush=True)
         return A_t, E_s
 
+    def pre_pred_X(mod, args):          # Async only: the attribute chain runs first, one MLPTower call per step
+        Ctx.x_step = int(round(float(args[0].item()) * T_X))
+        out[f"x{Ctx.x_step}_X_in_bits"] = pack_x(args[1])
+
     model.sample_E, model.sample_X, model.sample_E_infer, model.get_E_t = sample_E, sample_X, sample_E_infer, get_E_t
+    hook = None if sync else model.graph_encoder.pred_X.register_forward_pre_hook(pre_pred_X)
     saved = torch.Tensor.multinomial
     torch.Tensor.multinomial = _shim_multinomial
+    t0 = time.perf_counter()
     try:
         X, Y1h, E = model.sample(batch_size=32768, num_workers=0)
     finally:
         torch.Tensor.multinomial = saved
+    shim_total = time.perf_counter() - t0
+    if hook is not None:
+        hook.remove()
     out["Y"] = Y1h.argmax(1).numpy().astype(np.int32)
     out["final_X_bits"] = np.packbits(X[:, :, 1].T.contiguous().numpy().astype(np.uint8), axis=1)
     out["final_E_upper_nz"] = _upper_nz(E)
     out["config_json"] = np.frombuffer(json.dumps(cfg, sort_keys=True).encode(), dtype=np.uint8)
     np.savez_compressed(gu.golden_path(name), **out)
     print(f"{name}: wrote {gu.golden_path(name)} ({os.path.getsize(gu.golden_path(name)) / 1e3:.0f} kB); edges per step "
-          f"{[len(out[f'e{t}_E_out_upper_nz']) for t in range(T, 0, -1)]}")
+          f"{[len(out[f'e{t}_E_out_upper_nz']) for t in range(T_E, 0, -1)]}", flush=True)
 
-    # ---- the unmodified reference, timed (no shim, no state capture; only a stopwatch around get_E_t)
+    # ---- the reference timed: unmodified (no shim, no state capture; only a stopwatch around get_E_t) or the run above
     for k, v in orig.items():
         setattr(model, k, v)
-    step_s = []
+    if timed == "unmodified":
+        step_s = []
 
-    def timed_get_E_t(*a):
+        def timed_get_E_t(*a):
+            t0 = time.perf_counter()
+            r = orig["get_E_t"](*a)
+            step_s.append(time.perf_counter() - t0)
+            return r
+        model.get_E_t = timed_get_E_t
+        torch.manual_seed(0)
         t0 = time.perf_counter()
-        r = orig["get_E_t"](*a)
-        step_s.append(time.perf_counter() - t0)
-        return r
-    model.get_E_t = timed_get_E_t
-    torch.manual_seed(0)
-    t0 = time.perf_counter()
-    model.sample(batch_size=32768, num_workers=0)
-    total = time.perf_counter() - t0
+        model.sample(batch_size=32768, num_workers=0)
+        total = time.perf_counter() - t0
+    else:
+        step_s, total = shim_step_s, shim_total
     P = N * (N - 1) // 2
-    rec = {"what": "the reference's ModelSync.sample() (model/diffusion.py:797-905) run unmodified from /root/reference in the "
-                   "build container (torch CPU, dgl.sparse replaced by the torch stand-in of tools/gen_golden.py)",
-           "config": {k: cfg[k] for k in ("N", "F", "C", "T")}, "hidden": cfg["gnn_E"], "pairs_per_step": P,
+    steps = cfg["T"] if sync else T_E
+    what = ("ModelSync.sample() (model/diffusion.py:797-905)" if sync else "ModelAsync.sample() (model/diffusion.py:1295-1410)")
+    rec = {"what": f"the reference's {what} run from /root/reference in the build container (torch CPU, dgl.sparse replaced by "
+                   "the torch stand-in of tools/gen_golden.py); " +
+                   ("unmodified: torch.multinomial, no hooks" if timed == "unmodified" else
+                    "the fixture run itself: draws through the shared-RNG shim (threshold rule on Philox uniforms), state "
+                    "capture outside the per-step stopwatch"),
+           "timed": timed,
+           "config": {k: cfg[k] for k in ("N", "F", "C", "T", "T_X", "T_E") if k in cfg}, "hidden": cfg["gnn_E"],
+           "pairs_per_step": P,
            "torch_threads": torch.get_num_threads(), "cpu_count": os.cpu_count(), "torch": torch.__version__,
            "sample_wall_s": total, "get_E_t_wall_s_per_step": step_s,
-           "steps_per_sec": T / total, "structure_steps_per_sec": 1.0 / float(np.mean(step_s)),
+           "steps_per_sec": steps / total, "structure_steps_per_sec": 1.0 / float(np.mean(step_s)),
            "pair_scores_per_sec": P / float(np.mean(step_s)),
            "encoder_runs_per_step": -(-P // 32768)}
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
@@ -386,10 +419,15 @@ def run_large_case(name, gnn, diffusion):
 def main():
     torch.set_grad_enabled(False)
     gnn, diffusion = load_reference()
-    names = sys.argv[1:] or list(gu.CASES)
+    args = sys.argv[1:]
+    timed = "unmodified"
+    if "--timed-shim" in args:
+        args.remove("--timed-shim")
+        timed = "shim"
+    names = args or list(gu.CASES)
     for name in names:
         if name in gu.LARGE_CASES:
-            run_large_case(name, gnn, diffusion)
+            run_large_case(name, gnn, diffusion, timed=timed)
         else:
             run_case(name, gnn, diffusion)
 
