@@ -328,6 +328,7 @@ class BaseModel(nn.Module):
         if self._pair_ws is None or self._pair_ws.device != h.device:
             self._pair_ws = ops.pair_workspace(h.device)
         W1, b1, W2, b2 = pred_E.pair_params()
+        pred_E.check_relu63()                 # once per weight version: the kernel's ReLU range (gnn.LinkPredictor.relu63_bounds)
         ranges = [(0, n)] if plan is None else plan.pair_chunks()
         # zeroed once: the pair kernel rewrites every word it owns on each call and the others stay zero
         upper = self._buf("upper", (n if plan is None else plan.padded_pair_rows, bits_t.shape[1]), torch.int32, h.device,
@@ -557,6 +558,7 @@ class ModelSync(BaseModel):
         if self._pair_ws is None or self._pair_ws.device != dev:
             self._pair_ws = ops.pair_workspace(dev)
         W1, b1, W2, b2 = ge.pred_E.pair_params()
+        ge.pred_E.check_relu63()
         upper = self._buf("upper", (plan.padded_pair_rows, bits_t.shape[1]), torch.int32, dev, zero=True)
         with self.phase("pair"):
             ops.pair_score_sample(h, W1, b1, W2, b2, bits_t, tab_E, seed=seed, step=t, u=uE,

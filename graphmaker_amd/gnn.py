@@ -311,6 +311,49 @@ class LinkPredictor(nn.Module):
     def pair_params(self):
         return (self.mlp_out[0].weight, self.mlp_out[0].bias, self.mlp_out[2].weight, self.mlp_out[2].bias)
 
+    RELU63_LIMIT = 2.0 ** 63
+
+    @torch.no_grad()
+    def relu63_bounds(self):
+        """(largest possible |hidden activation| of the pair MLP, largest |second-layer weight|), from the weights alone.
+        The all-pairs kernel evaluates the hidden ReLU (model/gnn.py:229) as clamp01(x * 2^-63) against second-layer weights
+        scaled by 2^63: exact for x <= 0 and 2^-63 <= x <= 2^63; an activation above 2^63 would saturate and
+        a weight of 2^64 would overflow.  The bound follows the encoder: one-hot attributes select one first-layer column per
+        attribute, LayerNorm outputs are at most |gamma| sqrt(d) + |beta|, t lies in [0, 1]; every Linear is bounded by
+        |W| @ bound + |b|."""
+        def lin(m, v):
+            return m.weight.abs().float() @ v + (m.bias.abs().float() if m.bias is not None else 0.0)
+
+        enc = self.gnn_encoder
+        t0 = enc.mlp_in_t[0]
+        h_t = lin(enc.mlp_in_t[2], t0.weight.abs().float()[:, 0] + t0.bias.abs().float())
+        w0 = enc.mlp_in_X[0].weight.abs().float()
+        first = w0.reshape(w0.shape[0], enc.num_attrs_X, enc.num_classes_X).amax(2).sum(1) + enc.mlp_in_X[0].bias.abs().float()
+        hX, hY = [lin(enc.mlp_in_X[2], first)], [enc.emb_Y.weight.abs().float().amax(0)]
+        for layer in getattr(enc, enc._layers_attr):
+            for seq, acc in ((layer.update_X, hX), (layer.update_Y, hY)):
+                ln = seq[2]
+                acc.append(ln.weight.abs().float() * float(ln.normalized_shape[0]) ** 0.5 + ln.bias.abs().float())
+        h = lin(enc.mlp_out[2], lin(enc.mlp_out[0], torch.cat(hX + hY + [h_t])))
+        hid = lin(self.mlp_out[0], h * h)
+        return float(hid.max()), float(self.mlp_out[2].weight.abs().max())
+
+    def check_relu63(self):
+        """Warn (once per weight version; one small device-to-host read) when the weights do not rule out a hidden activation
+        outside the range in which the kernel's ReLU is exact.  Activations in (0, 2^-63) cannot be ruled out by a bound: they
+        come back rounded to a multiple of 2^-86, an absolute error below 2^-86 |w| per hidden unit."""
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if key == getattr(self, "_relu63_key", None):
+            return
+        self._relu63_key = key
+        hid, w2 = self.relu63_bounds()
+        if not (hid < self.RELU63_LIMIT and 2.0 * w2 < 2.0 * self.RELU63_LIMIT):
+            import warnings
+            warnings.warn(f"pred_E: the weights allow a pair-MLP hidden activation of up to {hid:.3g} and hold a second-layer "
+                          f"weight of {w2:.3g}; the all-pairs kernel's ReLU is exact only up to 2^63 = 9.2e18 (weights below "
+                          "2^64).  Larger activations saturate there where nn.ReLU would not (INTEGRATION.md, 'Numerical "
+                          "contract').", RuntimeWarning, stacklevel=3)
+
     def forward(self, t_float, X_t_one_hot, Y_real, A_t, src, dst):
         h = self.gnn_encoder(t_float, X_t_one_hot, Y_real, A_t)
         W1, b1, W2, b2 = self.pair_params()

@@ -369,6 +369,51 @@ def test_structure_step_vs_reference_and_oracle(dev, name):
             pytest.fail(f"{len(idx)} threshold-level flips vs the reference (not expected on these fixtures)")
 
 
+@pytest.mark.parametrize("name", ["sync_mid"])
+def test_product_pair_kernel_posteriors_against_the_reference_by_adversarial_keys(dev, name):
+    """The instantiation of the pair kernel that the product and the bench run (no debug outputs, in-kernel Philox) cannot
+    show its logits or posteriors; elsewhere it is tied to the reference through equal draws only.  Here the draws are made
+    to measure the posterior: Philox keys (seeds) are searched on the host for pairs whose uniform lands within
+    [BAND_LO, BAND_HI] of the REFERENCE's posterior threshold (fixture e{t}_E_prob), on either side.  For such a pair the
+    product kernel's draw equals the reference rule's draw exactly when its own posterior lies on the same side of u,
+    i.e. when |p_kernel - p_reference| is below that distance: a posterior error above POST_ATOL = 2e-6 would flip the
+    draws in the band.  All of them (>= 150 per case, both sides) must agree."""
+    ops = _ops()
+    cfg, g, model, towerX, towerE, pair, (Xm, Ym, Em) = _models(name, dev)
+    N = cfg["N"]
+    T = cfg["T"]
+    ns = model.noise_schedule
+    BAND_LO, BAND_HI = 2e-7, 4e-6
+    i, j = np.triu_indices(N, 1)
+    W1, b1, W2, b2 = model.graph_encoder.pred_E.pair_params()
+    checked = below = 0
+    for t in range(T, 0, -1):
+        ref_bits, _ = _bits_from_nz(g[f"e{t}_E_in_nz"], N)
+        bits_dev = bits_t(ref_bits, dev)
+        h_ref = t_(g[f"e{t}_h"], dev)
+        tab = model.transition.table_E(ns.alphas_host[t], ns.alpha_bars_host[t - 1], ns.alpha_bars_host[t])
+        p = g[f"e{t}_E_prob"].astype(np.float32)
+        s_, p1 = p[:, 0] + p[:, 1], p[:, 1]
+        got_here = 0
+        for seed in range(1, 40000):
+            u = orc.uniform_E(seed, t, N)
+            dist = u * s_ - p1                                   # the reference rule draws 1 iff this is negative
+            band = np.flatnonzero((np.abs(dist) >= BAND_LO) & (np.abs(dist) <= BAND_HI))
+            if not len(band):
+                continue
+            up = bits_np(ops.pair_score_sample(h_ref, W1, b1, W2, b2, bits_dev, tab, seed=seed, step=t))   # product instantiation
+            mine = (up[i[band], j[band] >> 5] >> (j[band] & 31).astype(np.uint32)) & 1
+            want = (dist[band] < 0).astype(np.uint32)
+            assert np.array_equal(mine, want), (f"t={t} seed={seed}: the product kernel's posterior is more than "
+                                                f"{np.abs(dist[band][mine != want]).min():.1e} away from the reference's")
+            got_here += len(band)
+            below += int(want.sum())
+            if got_here >= 60:
+                break
+        checked += got_here
+    assert checked >= 150 and 0 < below < checked, (checked, below)
+
+
 # opt-in reduced precision of the pair MLP's hidden layer: stated tolerances vs the REFERENCE's logits / posteriors, and the
 # bound on draws that may differ from the exact f32 path
 BF16_TOL = {"bf16x3": dict(logit=2e-5, post=2e-6, knife=1e-5), "bf16": dict(logit=3e-2, post=5e-3, knife=5e-3)}
@@ -649,6 +694,45 @@ def test_pair_kernel_planted_stall_word_ends_the_launch_at_once_and_is_reported(
     ops.check_pair_workspace(ws)                               # reported once, cleared with the report
     again = ops.pair_score_sample(h, W1, b1, W2, b2, bits, tab, seed=9, step=2, workspace=ws)
     assert torch.equal(again, clean)
+
+
+def test_pair_kernel_relu_outside_its_exact_range_is_as_documented(dev):
+    """The one place where the kernel's arithmetic is NOT the reference's (model/gnn.py:229 nn.ReLU): the hidden ReLU is
+    clamp01(x * 2^-63) against second-layer weights scaled by 2^63 (INTEGRATION.md "Numerical contract").
+    Inside [2^-63, 2^63] (and for x <= 0) that is exact; here one hidden unit is driven to 2^64 (saturates at 2^63) and one
+    to 2^-70 (1 + 2^-20) (rounded to a multiple of 2^-86): kernel == oracle bit for bit, and the distance to the exact
+    ReLU is the documented one."""
+    ops = _ops()
+    n = 70
+    g = torch.Generator(device="cpu").manual_seed(6)
+    h = (torch.randn(n, 128, generator=g) * 0.4)
+    W1 = torch.zeros(128, 128)
+    b1 = torch.zeros(128)
+    W2 = torch.zeros(2, 128)
+    b2 = torch.tensor([0.25, -0.5])
+    tab = orc.posterior_table_E(np.array([0.9, 0.1], np.float32), 0.58304191, 0.84701216, 0.49384356)
+    bits = bits_t(orc.bitmap_from_dense(np.zeros((n, n), np.int64)), dev)
+
+    def logits(b1_0, w):
+        b1c, W2c = b1.clone(), W2.clone()
+        b1c[0] = b1_0
+        W2c[1, 0] = w
+        _, lg, _ = ops.pair_score_sample(h.to(dev), W1.to(dev), b1c.to(dev), W2c.to(dev), b2.to(dev), bits, tab, seed=1, step=1,
+                                         want_debug=True)
+        pair = orc.PairMLP(W1.numpy(), b1c.numpy(), W2c.numpy(), b2.numpy())
+        _, o_lg, _ = orc.pair_score_sample(n, h.numpy(), pair, bits_np(bits), tab, seed=1, step=1, want_debug=True)
+        np.testing.assert_array_equal(lg.cpu().numpy(), o_lg)                    # kernel == oracle also out of range
+        return lg.cpu().numpy()
+
+    # in range: exact.  hid[0] = 2^40, w = 2^-40 -> logit 1 = 1 - 0.5
+    np.testing.assert_array_equal(logits(2.0 ** 40, 2.0 ** -40)[:, 1], np.float32(0.5))
+    # above 2^63: saturates.  exact ReLU: 2^64 * 2^-64 - 0.5 = 0.5; the kernel: 2^63 * 2^-64 - 0.5 = 0
+    np.testing.assert_array_equal(logits(2.0 ** 64, 2.0 ** -64)[:, 1], np.float32(0.0))
+    # below 2^-63: rounded to a multiple of 2^-86.  exact: 2^-70 (1 + 2^-20) * 2^60 - 0.5; the kernel drops the 2^-90 part
+    lg = logits(2.0 ** -70 * (1 + 2.0 ** -20), 2.0 ** 60)[:, 1]
+    np.testing.assert_array_equal(lg, np.float32(2.0 ** -10 - 0.5))
+    exact = np.float32(np.float32(2.0 ** -70 * (1 + 2.0 ** -20)) * np.float32(2.0 ** 60)) + np.float32(-0.5)
+    assert abs(float(lg[0]) - float(exact)) <= 2.0 ** -86 * 2.0 ** 60
 
 
 @pytest.mark.parametrize("hE,n", [(32, 333), (96, 130), (200, 257), (4, 64), (384, 70)])
@@ -940,10 +1024,13 @@ def test_full_size_step_properties_and_oracle_bands(dev, n, F, ht):
                 "node tower with the logit-difference head, full size")
 
 
-def test_eight_rank_shards_reproduce_single_gpu_step_at_amazon_computer_size(dev):
+@pytest.mark.parametrize("T", [3, 1])
+def test_eight_rank_shards_reproduce_single_gpu_step_at_amazon_computer_size(dev, T):
     """BASELINE.json configs[3]: the 8-rank plan at N=13752 (no 8-GPU box here).  All 8 ranks' tower stages, folded pair
     chunks and attribute rows are run one after the other on this GPU into shared buffers -- what the all-gathers
-    assemble -- and must equal the single-GPU step bit for bit."""
+    assemble -- and must equal the single-GPU step bit for bit.  T=3: the first step, from the prior draw (an
+    Erdos-Renyi E_t with self-loops); T=1: the last step, fed by the model's own sampled E_t and X_t (steps 3 and 2 run
+    free before it)."""
     import graphmaker_amd as gm
     from graphmaker_amd.parallel import ShardPlan
     ops = _ops()
@@ -957,15 +1044,19 @@ def test_eight_rank_shards_reproduce_single_gpu_step_at_amazon_computer_size(dev
     torch.manual_seed(8)
     model = gm.ModelSync(T=3, X_marginal=t_(Xm, dev), Y_marginal=t_(Ym, dev), E_marginal=t_(Em, dev), gnn_X_config=cfgX,
                          gnn_E_config=dict(hidden_E=128, **cfgX), num_nodes=n)
-    with torch.no_grad():
-        model.graph_encoder.pred_E.mlp_out[2].bias += torch.tensor([3.0, -3.0])
-    model = model.to(dev).eval()
-    seed, T = 31, 3
+    model = _sparse_regime(model).to(dev).eval()
+    seed = 31
     Y32 = ops.prior_Y(n, t_(Ym, dev), seed=seed)
     bits = ops.prior_E(n, float(Em[0]), float(Em[1]), dev, seed=seed)
     x_in, X_oh = ops.prior_X(n, t_(Xm, dev), seed=seed)
+    for t_before in range(3, T, -1):                                             # free-running up to the step under test
+        x_in, X_oh, bits = model.denoise_step(t_before, x_in, X_oh, Y32, bits, seed)
+    if T < 3:
+        E_in = ops.dense_from_bitmap(bits, n)
+        assert int(E_in.diagonal().sum()) == 0 and n < int(E_in.sum()) // 2 < 400 * n      # a sampled graph, not the prior's
+        del E_in
     A_t = ops.adjacency_from_bitmap(bits, n)
-    t_float = torch.tensor([1.0], dtype=torch.float32, device=dev)
+    t_float = torch.tensor([T / 3], dtype=torch.float32, device=dev)
     tab_E, tab_X = model.step_tables(T)
     enc, pred_X = model.graph_encoder.pred_E.gnn_encoder, model.graph_encoder.pred_X
     W1, b1, W2, b2 = model.graph_encoder.pred_E.pair_params()
@@ -1005,6 +1096,98 @@ def test_eight_rank_shards_reproduce_single_gpu_step_at_amazon_computer_size(dev
                                   diff=True)
     assert torch.equal(ops.symmetrize_upper(up[:n].contiguous(), n), bits1)
     assert torch.equal(xs, xs_full)
+
+
+def _amazon_marginals(n, F, C, density, seed):
+    rs = np.random.RandomState(seed)
+    p1 = rs.uniform(0.002, 0.02, size=F).astype(np.float32)
+    return (np.stack([1 - p1, p1], 1).astype(np.float32), np.full(C, 1.0 / C, np.float32),
+            np.array([1 - density, density], np.float32))
+
+
+def _sparse_regime(model):
+    """Untrained heads shifted into a trained model's sparse regime (as bench.py does): the trajectory keeps a sparse graph."""
+    with torch.no_grad():
+        model.graph_encoder.pred_E.mlp_out[2].bias += torch.tensor([3.0, -3.0])
+        bx = model.graph_encoder.pred_X.mlp_out[2].bias
+        bx[0::2] += 2.0
+        bx[1::2] -= 2.0
+    return model
+
+
+def _oracle_parts(model, is_mlp_X):
+    sdX = {k: v.detach().cpu().numpy() for k, v in model.graph_encoder.pred_X.state_dict().items()}
+    sdE = {k: v.detach().cpu().numpy() for k, v in model.graph_encoder.pred_E.state_dict().items()}
+    return (orc.Tower.from_state_dict(sdX, is_mlp=is_mlp_X), orc.Tower.from_state_dict(sdE, is_mlp=False, prefix="gnn_encoder."),
+            orc.PairMLP(sdE["mlp_out.0.weight"], sdE["mlp_out.0.bias"], sdE["mlp_out.2.weight"], sdE["mlp_out.2.bias"]))
+
+
+@pytest.mark.parametrize("n,F,C,density", [(7650, 745, 8, 4.07e-3), (13752, 767, 10, 2.60e-3)])
+def test_amazon_size_whole_sync_sample_bit_identical_to_oracle(dev, n, F, C, density):
+    """BASELINE.json configs[2] / [3] and north_star's target: a FULL Sync sample (priors, all T=3 reverse steps, all N^2 pairs
+    of every step, free-running: steps t=2,1 see a model-sampled E_t, other posterior tables, pred_X on A_t of the sampled
+    graph -- model/diffusion.py:847-896 x T) at amazon_photo and amazon_computer size.  Attributes, labels and the edge
+    list must equal the CPU oracle's trajectory on the same Philox key bit for bit."""
+    import graphmaker_amd as gm
+    Xm, Ym, Em = _amazon_marginals(n, F, C, density, n + 1)
+    cfgX = dict(hidden_t=16, hidden_X=512, hidden_Y=64, num_gnn_layers=2, dropout=0.0)
+    torch.manual_seed(n + 1)
+    model = _sparse_regime(gm.ModelSync(T=3, X_marginal=t_(Xm, dev), Y_marginal=t_(Ym, dev), E_marginal=t_(Em, dev),
+                                        gnn_X_config=cfgX, gnn_E_config=dict(hidden_E=128, **cfgX), num_nodes=n)).to(dev).eval()
+    towerX, towerE, pair = _oracle_parts(model, False)
+    seed = 90210
+    X, Y1h, el = model.sample(seed=seed, dense=False)
+    ns = model.noise_schedule
+    x, y, bits = orc.sample_sync(3, n, Xm, Ym, Em, towerX, towerE, pair, seed, sched=(ns.alphas_host, ns.alpha_bars_host))
+    np.testing.assert_array_equal(Y1h.argmax(1).cpu().numpy(), y)
+    np.testing.assert_array_equal(X[:, :, 1].T.cpu().numpy().astype(np.uint8), x)
+    ei, ej = orc.upper_edges_from_bitmap(bits, n)
+    np.testing.assert_array_equal(el.cpu().numpy(), np.stack([ei, ej]))
+    assert n < len(ei) < n * 400 and 0 < int(x.sum()) < n * F // 4, "degenerate sample: the comparison would be vacuous"
+
+
+def test_amazon_computer_async_trajectory_against_the_oracle(dev):
+    """configs/amazon_computer/train_Async.yaml (MLPTower hidden_X=1024, T_X=7, T_E=9) at N=13752, F=767: the whole attribute
+    chain (7 steps, model/diffusion.py:1330-1358), the E prior, and the first 3 of the 9 structure steps (:1379-1401, each
+    on the final attributes and the previous step's sampled graph), free-running; the state after every step equals the
+    oracle's bit for bit."""
+    import graphmaker_amd as gm
+    ops = _ops()
+    n, F, C = 13752, 767, 10
+    Xm, Ym, Em = _amazon_marginals(n, F, C, 2.6e-3, 12)
+    torch.manual_seed(12)
+    model = _sparse_regime(gm.ModelAsync(
+        T_X=7, T_E=9, X_marginal=t_(Xm, dev), Y_marginal=t_(Ym, dev), E_marginal=t_(Em, dev),
+        mlp_X_config=dict(hidden_t=16, hidden_X=1024, hidden_Y=64, num_mlp_layers=2, dropout=0.0),
+        gnn_E_config=dict(hidden_t=16, hidden_X=512, hidden_Y=64, hidden_E=128, num_gnn_layers=2, dropout=0.0),
+        num_nodes=n)).to(dev).eval()
+    towerX, towerE, pair = _oracle_parts(model, True)
+    seed = 4711
+    Y32 = ops.prior_Y(n, t_(Ym, dev), seed=seed)
+    y = orc.prior_Y(n, Ym, seed=seed)
+    np.testing.assert_array_equal(Y32.cpu().numpy(), y)
+    x, oh = ops.prior_X(n, t_(Xm, dev), seed=seed)
+    xo = orc.prior_X(n, Xm, seed=seed)
+    _, aX, abX = orc.noise_schedule(7)
+    _, aE, abE = orc.noise_schedule(9)
+    for t in range(7, 0, -1):
+        x, oh = model.attribute_step(t, x, oh, Y32, seed)
+        diff = towerX.forward(np.float32(t / 7), orc.onehot_from_x(xo), y, diff_head=True)
+        xo = orc.attr_posterior_sample(diff, xo, orc.posterior_tables_X(Xm, aX[t], abX[t - 1], abX[t]), seed=seed, step=t, diff=True)
+        np.testing.assert_array_equal(x.cpu().numpy(), xo, err_msg=f"attribute step t={t}")
+    assert 0 < int(xo.sum()) < n * F // 4
+    bits = ops.prior_E(n, float(Em[0]), float(Em[1]), dev, seed=seed)
+    bo = orc.prior_E(n, Em, seed=seed)
+    oh_o = orc.onehot_from_x(xo)
+    for t in range(9, 6, -1):
+        bits = model.structure_step(t, oh, Y32, bits, seed, reuse_X=t != 9)
+        rp, ci = orc.csr_from_bitmap(bo, n)
+        h = towerE.forward(np.float32(t / 9), oh_o, y, rp, ci)
+        up = orc.pair_score_sample(n, h, pair, bo, orc.posterior_table_E(Em, aE[t], abE[t - 1], abE[t]), seed=seed, step=t)
+        bo = orc.symmetrize_upper(up, n)
+        np.testing.assert_array_equal(bits_np(bits), bo, err_msg=f"structure step t={t}")
+        assert n < int(np.unpackbits(bo.view(np.uint8)).sum()) // 2 < n * 400
+    ops.check_pair_workspace(model._pair_ws)
 
 
 def test_amazon_computer_async_attribute_tower_hidden_1024(dev):

@@ -191,3 +191,28 @@ def test_pair_kernel_handshake_protocol_is_bounded(tmp_path):
                     os.path.join(root, "tests", "host", "pair_protocol_test.cpp"), "-o", exe], check=True)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr
+
+
+def test_relu63_guard_warns_only_for_weights_that_allow_out_of_range_activations():
+    """The all-pairs kernel's hidden ReLU is exact for activations <= 0 or within [2^-63, 2^63] (the reference's
+    nn.ReLU, model/gnn.py:229, is exact everywhere).  The weights-only bound of LinkPredictor.relu63_bounds() must stay
+    silent for a reference-initialised denoiser and warn when a weight makes an activation of 2^64 possible."""
+    import warnings
+    import graphmaker_amd as gm
+    cfg = gu.CASES["sync_small"]
+    Xm, Ym, Em = gu.marginals(cfg)
+    model = gm.ModelSync(T=3, X_marginal=torch.from_numpy(Xm), Y_marginal=torch.from_numpy(Ym), E_marginal=torch.from_numpy(Em),
+                         gnn_X_config=cfg["gnn_X"], gnn_E_config=cfg["gnn_E"], num_nodes=cfg["N"])
+    pred_E = model.graph_encoder.pred_E
+    hid, w2 = pred_E.relu63_bounds()
+    assert 0 < hid < 2.0 ** 40 and 0 < w2 < 10
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        pred_E.check_relu63()
+    with torch.no_grad():
+        pred_E.mlp_out[0].bias[0] = 2.0 ** 64
+    with pytest.warns(RuntimeWarning, match="2\\^63"):
+        pred_E.check_relu63()
+    with warnings.catch_warnings():                    # once per weight version
+        warnings.simplefilter("error")
+        pred_E.check_relu63()
