@@ -41,7 +41,18 @@ SMALL = dict(name="cora_shape", N=2708, F=1433, C=7, T=3, density=1.44e-3,
 SBM100K = dict(name="sbm_100k", N=100000, F=1433, C=7, T=3, density=4.0e-5,
                gnn_X=dict(hidden_t=32, hidden_X=512, hidden_Y=64, num_gnn_layers=2, dropout=0.0),
                gnn_E=dict(hidden_t=32, hidden_X=512, hidden_Y=64, hidden_E=128, num_gnn_layers=2, dropout=0.0))
-WORKLOADS = {"amazon_computer": WORKLOAD, "cora_shape": SMALL, "sbm_100k": SBM100K}
+# BASELINE.json configs[2]: amazon_photo, configs/amazon_photo/train_Sync.yaml
+PHOTO = dict(name="amazon_photo", N=7650, F=745, C=8, T=3, density=4.07e-3,
+             gnn_X=dict(hidden_t=16, hidden_X=512, hidden_Y=64, num_gnn_layers=2, dropout=0.0),
+             gnn_E=dict(hidden_t=16, hidden_X=512, hidden_Y=64, hidden_E=128, num_gnn_layers=2, dropout=0.0))
+# BASELINE.json configs[1]: Cora Async, configs/cora/train_Async.yaml (T_X=6, T_E=9).  The Async path has no single "step" that
+# does everything (attribute steps carry no graph, structure steps no attribute tower): this workload times WHOLE samples
+# (priors + 6 attribute steps + 9 structure steps) and reports samples/s -- never the headline line.
+CORA_ASYNC = dict(name="cora_async", variant="Async", N=2708, F=1433, C=7, T_X=6, T_E=9, density=1.44e-3,
+                  mlp_X=dict(hidden_t=32, hidden_X=512, hidden_Y=64, num_mlp_layers=2, dropout=0.0),
+                  gnn_E=dict(hidden_t=32, hidden_X=512, hidden_Y=64, hidden_E=128, num_gnn_layers=2, dropout=0.0))
+WORKLOADS = {"amazon_computer": WORKLOAD, "cora_shape": SMALL, "sbm_100k": SBM100K, "amazon_photo": PHOTO,
+             "cora_async": CORA_ASYNC}
 
 FLOP_PER_PAIR = 2 * 128 * 128 + 2 * 128 * 2 + 128      # 33,408
 F32_MFMA_PEAK_TFLOPS = 157.3                            # MI355X_MICROARCH.md: dense f32 matrix peak
@@ -59,8 +70,12 @@ def build_model(wl, dev):
     d = np.float32(wl["density"])
     Em = torch.tensor([1.0 - d, d], dtype=torch.float32, device=dev)
     torch.manual_seed(0)
-    model = gm.ModelSync(T=wl["T"], X_marginal=Xm, Y_marginal=Ym, E_marginal=Em, gnn_X_config=wl["gnn_X"],
-                         gnn_E_config=wl["gnn_E"], num_nodes=wl["N"])
+    if wl.get("variant") == "Async":
+        model = gm.ModelAsync(T_X=wl["T_X"], T_E=wl["T_E"], X_marginal=Xm, Y_marginal=Ym, E_marginal=Em,
+                              mlp_X_config=wl["mlp_X"], gnn_E_config=wl["gnn_E"], num_nodes=wl["N"])
+    else:
+        model = gm.ModelSync(T=wl["T"], X_marginal=Xm, Y_marginal=Ym, E_marginal=Em, gnn_X_config=wl["gnn_X"],
+                             gnn_E_config=wl["gnn_E"], num_nodes=wl["N"])
     with torch.no_grad():
         b = model.graph_encoder.pred_E.mlp_out[2].bias
         b[0] += 3.0
@@ -113,15 +128,9 @@ def cpu_baseline(wl, model, state, budget_rows=768, threads=None):
     as_ref_s = t_tower_e * nbatch + t_pair * P / p_sample + t_tower_x
     # the reference's own ModelSync.sample() cannot run on the GPU box (no reference code travels): its figure is the one
     # measured in the build container by tools/gen_golden.py at Cora shape, quoted beside the port
-    ref = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "ref_cpu_cora_sync.json")) as fh:
-            r = json.load(fh)
-        ref = {"source": "profiles/ref_cpu_cora_sync.json (build container, not this box)", "workload": "cora shape N=2708 F=1433",
-               "steps_per_sec": r["steps_per_sec"], "pair_scores_per_sec": r["pair_scores_per_sec"],
-               "torch_threads": r["torch_threads"], "encoder_runs_per_step": r["encoder_runs_per_step"]}
-    except Exception:
-        pass
+    ref = reference_cpu_figures()
+    # sanity of the derived figure: the same derivation at the shapes where the reference WAS run should land near the
+    # measured rate (it uses this box's oracle towers, the measurement the container's torch: same order of magnitude)
     return {"value": 1.0 / step_s, "unit": "steps/s", "cores": orc.get_threads(), "kind": "port", "reference_cpu": ref,
             "pair_scores_per_sec": p_sample / t_pair,
             "as_reference_cost_structure": {"steps_per_sec": 1.0 / as_ref_s, "encoder_runs_per_step": nbatch,
@@ -130,6 +139,48 @@ def cpu_baseline(wl, model, state, budget_rows=768, threads=None):
             "sample": f"CSR + edge tower ({t_tower_e:.1f} s) and node tower + attribute draw ({t_tower_x:.1f} s) on all {n} "
                       f"nodes; pair stage on rows [0,{rows}) = {p_sample} of {P} pairs ({t_pair:.1f} s), extrapolated by "
                       "pair count; encoder hoisted once per step (the reference re-runs it per 32768-pair batch)"}
+
+
+def cpu_baseline_async(wl, model, state, budget_rows=0, threads=None):
+    """The CPU oracle's whole Async sample (oracle gmo_sample_async, kind "port", encoder hoisted once per step) on this host:
+    small enough at Cora shape to run whole (a few seconds)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as orc
+    if threads:
+        orc.set_threads(threads)
+    sdX = {k: v.detach().cpu().numpy() for k, v in model.graph_encoder.pred_X.state_dict().items()}
+    sdE = {k: v.detach().cpu().numpy() for k, v in model.graph_encoder.pred_E.state_dict().items()}
+    towerX = orc.Tower.from_state_dict(sdX, is_mlp=True)
+    towerE = orc.Tower.from_state_dict(sdE, is_mlp=False, prefix="gnn_encoder.")
+    pair = orc.PairMLP(sdE["mlp_out.0.weight"], sdE["mlp_out.0.bias"], sdE["mlp_out.2.weight"], sdE["mlp_out.2.bias"])
+    nx, ne = model.noise_schedule_X, model.noise_schedule_E
+    t0 = time.perf_counter()
+    orc.sample_async(wl["T_X"], wl["T_E"], wl["N"], model.X_marginal.cpu().numpy(), model.Y_marginal.cpu().numpy(),
+                     model.E_marginal.cpu().numpy(), towerX, towerE, pair, 1000,
+                     schedX=(nx.alphas_host, nx.alpha_bars_host), schedE=(ne.alphas_host, ne.alpha_bars_host))
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "samples/s", "cores": orc.get_threads(), "kind": "port",
+            "reference_cpu": reference_cpu_figures(),
+            "sample": f"one whole Async sample of the oracle ({dt:.1f} s): all {wl['T_X']} attribute steps and {wl['T_E']} "
+                      "structure steps on all pairs; encoder hoisted once per step (the reference re-runs it per 32768-pair batch)"}
+
+
+def reference_cpu_figures():
+    """The reference's own sample() timed in the build container by tools/gen_golden.py (it cannot run on the GPU box: no
+    reference code travels): Cora Sync, Cora Async and amazon_photo Sync, whichever files are present."""
+    out = []
+    for name, what in (("cora_sync", "cora Sync N=2708 F=1433"), ("cora_async", "cora Async N=2708 F=1433 T_X=6 T_E=9"),
+                       ("photo_sync", "amazon_photo Sync N=7650 F=745")):
+        try:
+            with open(os.path.join(ROOT, "profiles", f"ref_cpu_{name}.json")) as fh:
+                r = json.load(fh)
+            out.append({"source": f"profiles/ref_cpu_{name}.json (build container, not this box)", "workload": what,
+                        "structure_steps_per_sec": r["structure_steps_per_sec"], "steps_per_sec": r["steps_per_sec"],
+                        "pair_scores_per_sec": r["pair_scores_per_sec"], "torch_threads": r["torch_threads"],
+                        "encoder_runs_per_step": r["encoder_runs_per_step"], "timed": r.get("timed", "unmodified")})
+        except Exception:
+            continue
+    return out or None
 
 
 def _time_ms(fn, reps=20, warm=3):
@@ -246,6 +297,10 @@ def main():
                     help="diagnostic, one GPU: time rank --rehearse-rank's share of a G-rank step with the collectives "
                          "replaced by no-ops (results are not meaningful, only the per-rank compute + launch time is)")
     ap.add_argument("--rehearse-rank", type=int, default=0)
+    ap.add_argument("--replicate-graph-part", action="store_true",
+                    help="N > 1: ShardPlan(replicate_graph_part=True) -- every rank runs input projections + message passing on "
+                         "all rows, only mlp_out is row-sharded (collectives per step: h + X + edge segments); default: every "
+                         "stage row-sharded with an all-gather of the layer input before each message-passing layer")
     args = ap.parse_args()
 
     wl = WORKLOADS[args.workload]
@@ -264,17 +319,19 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         from graphmaker_amd.parallel import ShardPlan
-        plan = ShardPlan.make(wl["N"], world, rank)
+        plan = ShardPlan.make(wl["N"], world, rank, replicate_graph_part=args.replicate_graph_part)
     elif args.rehearse_world > 1:
         from graphmaker_amd import parallel
-        plan = parallel.ShardPlan.make(wl["N"], args.rehearse_world, args.rehearse_rank)
+        plan = parallel.ShardPlan.make(wl["N"], args.rehearse_world, args.rehearse_rank,
+                                       replicate_graph_part=args.replicate_graph_part)
         parallel._all_gather = lambda out, inp, group, async_op=False: parallel._Done()   # pack / unpack kernels still run
         args.no_extras = args.no_cpu_baseline = True
 
     from graphmaker_amd import ops
     model = build_model(wl, dev)
     model.pair_precision = args.pair_precision
-    n, T = wl["N"], wl["T"]
+    is_async = wl.get("variant") == "Async"
+    n, T = wl["N"], wl["T_E"] if is_async else wl["T"]
     Em = model.transition.E_marginal_host
     Y32 = ops.prior_Y(n, model.Y_marginal, seed=0)
     bits = ops.prior_E(n, float(Em[0]), float(Em[1]), dev, seed=0)
@@ -287,6 +344,8 @@ def main():
         torch.cuda.synchronize()
 
     def one_step(k):
+        if is_async:        # a whole Async sample: priors, T_X attribute steps, T_E structure steps (see CORA_ASYNC)
+            return model.sample(seed=1000 + k, dense=False, plan=plan)
         return model.denoise_step(T, x, oh, Y32, bits, seed=1000 + k, plan=plan)
 
     barrier()                                   # communicator set-up happens here, not in the timed region
@@ -310,6 +369,7 @@ def main():
     # whose pair kernel gave up on an LDS hand-shake, or whose adjacency was truncated, cannot be reported as a valid rate
     ops.check_pair_workspace(model._pair_ws)
     model._csr_ws(dev).check()
+    model._finish(oh, Y32, bits, dense=False)   # ... and the multi-GPU edge-exchange overflow flag (same check sample() ends with)
     phases = {k: float(np.mean(v)) for k, v in model.phase_times_ms().items()}
     model.enable_phase_timing(True)             # the phase breakdown: untimed steps with every phase bracketed
     n_diag = max(1, min(args.steps, 5))
@@ -318,14 +378,19 @@ def main():
     barrier()
     phases = {**{k: float(np.mean(v)) for k, v in model.phase_times_ms().items()}, **phases}   # "pair": the timed steps'
     model.enable_phase_timing(False)
+    phases_rank0, enqueue_rank0 = dict(phases), enqueue_ms
     if dist.is_initialized():
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        # max over ranks of the wall time (the contract) AND of every phase and the host enqueue time: one slow rank, or one
+        # rank whose all-gather waits are long, must show in the line, not only rank 0's view
+        keys = sorted(phases)
+        vals = torch.tensor([elapsed, enqueue_ms] + [phases[k] for k in keys], dtype=torch.float64, device=dev)
+        dist.all_reduce(vals, op=dist.ReduceOp.MAX)
+        elapsed, enqueue_ms = float(vals[0].item()), float(vals[1].item())
+        phases = {k: float(v) for k, v in zip(keys, vals[2:].tolist())}
 
     # a whole Sync sample (priors + all T reverse steps, free-running state) on all ranks, outside the timed steps
     full_sample_ms = None
-    if not args.no_extras:
+    if not args.no_extras and not is_async:
         model.sample(seed=6, dense=False, plan=plan)       # untimed: first-use allocations of the trajectory's buffers
         barrier()
         t0 = time.perf_counter()
@@ -353,35 +418,53 @@ def main():
             continue
     if args.rehearse_world > 1:
         print(json.dumps({"rehearsal": f"rank {plan.rank} of {plan.world}, collectives replaced by no-ops, one GPU",
+                          "tower_split": "graph part replicated, mlp_out row-sharded" if plan.replicate_graph_part else
+                          "every stage row-sharded",
                           "ms_per_step": ms_per_step, "host_enqueue_ms_per_step": enqueue_ms, "phases_ms": phases,
                           "pairs_this_rank": pairs_here,
                           "pair_TFLOPs": achieved}))
         return
     if rank == 0:
         res = {
-            "metric": f"denoising steps/sec ({wl['name']} Sync step); pair-scores/sec in pair_scores_per_sec",
-            "value": args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": (f"denoising steps/sec ({wl['name']} Sync step); pair-scores/sec in pair_scores_per_sec" if not is_async else
+                       f"whole samples/sec ({wl['name']}: priors + {wl['T_X']} attribute steps + {wl['T_E']} structure steps); "
+                       "pair-scores/sec in pair_scores_per_sec"),
+            "value": args.steps / elapsed, "unit": "samples/s" if is_async else "steps/s", "n_gpus": world,
+            "rccl_world": dist.get_world_size() if dist.is_initialized() else 1,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if args.pair_precision == "f32" else f"f32 (pair MLP hidden layer on {args.pair_precision} MFMA, opt-in)",
             "data": "synthetic",
-            "config": {"workload": f"{wl['name']} GraphMaker-Sync reverse step t=T: N={n} F={wl['F']} C={wl['C']} "
-                                   f"hidden 512/64/{wl['gnn_E']['hidden_t']}/128, L=2; E_t = prior draw, nnz={nnz}; "
-                                   f"all P={P} unordered pairs (N^2 equivalent {2 * P + n})",
-                       "pairs_per_step": P, "parallelism": "single GPU" if world == 1 else
-                       f"{world} ranks: folded row chunks of the pair matrix, row-sharded towers, all-gathers of "
-                       "layer inputs, h, E rows and X over RCCL"},
-            "pair_scores_per_sec": P / (elapsed / args.steps),
+            "config": {"workload": (f"{wl['name']} GraphMaker-Sync reverse step t=T: N={n} F={wl['F']} C={wl['C']} "
+                                    f"hidden 512/64/{wl['gnn_E']['hidden_t']}/128, L=2; E_t = prior draw, nnz={nnz}; "
+                                    f"all P={P} unordered pairs (N^2 equivalent {2 * P + n})") if not is_async else
+                                   (f"{wl['name']} GraphMaker-Async whole sample: N={n} F={wl['F']} C={wl['C']} T_X={wl['T_X']} "
+                                    f"T_E={wl['T_E']}, hidden 512/64/{wl['gnn_E']['hidden_t']}/128, L=2; free-running from the "
+                                    f"priors; all P={P} unordered pairs in each of the {wl['T_E']} structure steps"),
+                       "pairs_per_step": P * (wl["T_E"] if is_async else 1), "parallelism": "single GPU" if world == 1 else
+                       (f"{world} ranks: folded row chunks of the pair matrix; towers: graph part replicated, mlp_out "
+                        "row-sharded; all-gathers of h, X and edge segments over RCCL" if plan.replicate_graph_part else
+                        f"{world} ranks: folded row chunks of the pair matrix, row-sharded tower stages, all-gathers of "
+                        "layer inputs, h, X and edge segments over RCCL")},
+            "pair_scores_per_sec": P * (wl["T_E"] if is_async else 1) / (elapsed / args.steps),
             "pair_phase_scores_per_sec": pairs_here * (world if plan else 1) / (pair_ms * 1e-3),
-            "phases_ms_rank0": phases,
+            "phases_ms_rank0": phases_rank0,
+            "phases_ms_max_over_ranks": phases,
             "phases_note": "pair: events inside the timed steps; the other phases: extra untimed steps with every phase bracketed "
-                           "(each event record idles the GPU for 5-10 us, so those steps run slower than the timed ones)",
-            "host_enqueue_ms_per_step_rank0": enqueue_ms,
+                           "(each event record idles the GPU for 5-10 us, so those steps run slower than the timed ones); per "
+                           "occurrence (an Async sample has several of each)",
+            # what the step's stream spent WAITING for each collective that is waited for outside the towers (the layer-input
+            # gathers of the stage-sharded towers are started and waited for inside the `towers` phase and show there)
+            "exposed_allgather_ms_max_over_ranks": {k: phases[k] for k in ("allgather_h", "allgather_E", "allgather_X")
+                                                    if k in phases} if plan is not None else None,
+            "host_enqueue_ms_per_step_rank0": enqueue_rank0,
+            "host_enqueue_ms_per_step_max_over_ranks": enqueue_ms,
             "roofline": {"kernel": "gm::k_pair_score_sample", "bound": "mfma", "achieved": achieved,
                          "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
                          "traffic": traffic, "traffic_source": traffic_source, "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch_rank0": pairs_here,
                          "launch_ms": pair_ms},
         }
-        if world == 1 and not args.no_extras:
+        if world == 1 and not args.no_extras and not is_async:
             res["roofline_secondary"] = secondary_rooflines(wl, model, bits, dev)
             # both towers as they run inside the timed step: the GEMM FLOP the kernels EXECUTE over the time both take.
             # The first layer runs on the attributes, not their one-hot image (K = F, or no GEMM at all when the sparse
@@ -407,8 +490,9 @@ def main():
             res["full_sample_ms"] = full_sample_ms
         if not args.no_cpu_baseline and world == 1:
             try:
-                res["cpu_baseline"] = cpu_baseline(wl, model, (x, oh, Y32, bits), budget_rows=args.cpu_rows,
-                                                   threads=int(os.environ.get("OMP_NUM_THREADS", "0")) or None)
+                res["cpu_baseline"] = (cpu_baseline_async if is_async else cpu_baseline)(
+                    wl, model, (x, oh, Y32, bits), budget_rows=args.cpu_rows,
+                    threads=int(os.environ.get("OMP_NUM_THREADS", "0")) or None)
             except Exception as exc:  # the baseline must never take the GPU number down with it
                 res["cpu_baseline"] = {"value": None, "error": repr(exc)}
         print(json.dumps(res))

@@ -310,7 +310,7 @@ class BaseModel(nn.Module):
         n = self.num_nodes
         with self.phase("csr"):      # built into the model's workspace: no host read of the edge count in a step
             A_t = ops.adjacency_from_bitmap(bits_t, n, workspace=self._csr_ws(bits_t.device),
-                                            rows=None if plan is None else plan.node_range())
+                                            rows=None if plan is None else plan.adjacency_rows())
         if after_csr is not None:
             after_csr(A_t)
         enc = pred_E.gnn_encoder
@@ -522,8 +522,8 @@ class ModelSync(BaseModel):
         n, dev = self.num_nodes, x.device
         ge = self.graph_encoder
         enc, pred_X = ge.pred_E.gnn_encoder, ge.pred_X
-        with self.phase("csr"):      # only the rows this rank aggregates (its node block)
-            A_t = ops.adjacency_from_bitmap(bits_t, n, workspace=self._csr_ws(dev), rows=plan.node_range())
+        with self.phase("csr"):      # only the rows this rank aggregates (its node block, or all with a replicated graph part)
+            A_t = ops.adjacency_from_bitmap(bits_t, n, workspace=self._csr_ws(dev), rows=plan.adjacency_rows())
         h_pad = self._buf("h_pad", (plan.world * plan.node_rows, enc._dims.out_size), torch.float32, dev)
         logits = self._buf("logit_diff", (n, self.num_attrs_X), torch.float32, dev)      # l1 - l0 per attribute (_logits_fn)
         x_pad = self._buf("x_pad", (plan.world * plan.node_rows, x.shape[1]), torch.uint8, dev)

@@ -236,6 +236,13 @@ class _TowerBase(nn.Module):
         (d, ptrs), ws = self._head(diff_head), self._workspace(n, dev)
         prep = self._prep()
         rows = plan.node_range()
+        if plan.replicate_graph_part and not self._is_mlp:
+            # input projections + message passing on all n rows on every rank (no exchange), mlp_out on this rank's rows
+            reuse = reuse_X and getattr(self, "_hx0_rows", None) == (n, None)
+            self._hx0_rows = (n, None)
+            ops.tower_forward(d, ptrs, n, t, None if reuse else X, Y32, A_t, ws, rows=rows, out=out, prep=prep,
+                              x_u8=None if reuse else x_u8, sparse_X=self._sparse_X)
+            return
         if reuse_X and getattr(self, "_hx0_rows", None) == (n, rows):
             X = x_u8 = None                        # mlp_in_X(X) of these rows is still in the workspace
         self._hx0_rows = (n, rows)

@@ -32,11 +32,25 @@ class ShardPlan:
     rank: int
     chunk_rows: int          # a: rows per folded chunk (multiple of 64 = the pair kernel's tile edge)
     node_rows: int           # rows per rank of the contiguous node partition (towers, attributes)
+    # How the GNN towers are split (the pair matrix, the attribute draw and the edge exchange are the same either way):
+    #   False: every stage row-sharded; the [h_X | h_Y] rows (N x 576 fp32) are all-gathered before each message-passing
+    #          layer -- least compute per rank (1/G of everything), 2 extra all-gathers per tower and step;
+    #   True:  the north-star / SURVEY 8e layout: every rank runs the input projections and the message-passing layers on
+    #          ALL N rows (redundantly, no exchange), only the row-independent output MLP (mlp_out, ~60 % of a tower's
+    #          FLOP) is row-sharded; collectives per step = h + X + edge segments only.
+    # Results are bit-identical (same kernels on the same rows); which is faster depends on the all-gather latency of the
+    # machine (DESIGN.md 7 has both variants' per-rank compute and bytes).
+    replicate_graph_part: bool = False
 
     @staticmethod
-    def make(n, world, rank, align=64):
+    def make(n, world, rank, align=64, replicate_graph_part=False):
         a = _ceil_div(_ceil_div(n, 2 * world), align) * align
-        return ShardPlan(n=n, world=world, rank=rank, chunk_rows=a, node_rows=_ceil_div(n, world))
+        return ShardPlan(n=n, world=world, rank=rank, chunk_rows=a, node_rows=_ceil_div(n, world),
+                         replicate_graph_part=replicate_graph_part)
+
+    def adjacency_rows(self):
+        """The rows of A_t a rank aggregates: its node block, or all of them when the graph part is replicated."""
+        return None if self.replicate_graph_part else self.node_range()
 
     def chunk(self, c):
         a, n = self.chunk_rows, self.n

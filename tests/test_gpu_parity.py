@@ -1090,6 +1090,14 @@ def test_eight_rank_shards_reproduce_single_gpu_step_at_amazon_computer_size(dev
     staged(enc, h)
     staged(pred_X, lg, diff_head=True)
     assert torch.equal(h, h_full) and torch.equal(lg, lg_full)
+    # the other tower split (ShardPlan.replicate_graph_part, SURVEY.md 8e option 1): graph part on all rows, mlp_out per rank
+    h2, lg2 = torch.full_like(h_full, float("nan")), torch.full_like(lg_full, float("nan"))
+    for r in range(world):
+        pl = ShardPlan.make(n, world, r, replicate_graph_part=True)
+        for tower, out, dh in ((enc, h2, False), (pred_X, lg2, True)):
+            for _ in tower._sharded_stages(t_float, X_oh, Y32, A_t, pl, None, out, None, x_u8=x_in, diff_head=dh):
+                raise AssertionError("the replicated-graph-part tower has no exchange stage")
+    assert torch.equal(h2, h_full) and torch.equal(lg2, lg_full)
     for pl in plans:
         ops.pair_score_sample(h, W1, b1, W2, b2, bits, tab_E, seed=seed, step=T, row_ranges=pl.pair_chunks(), out_upper=up)
         ops.attr_posterior_sample(lg, x_in, t_(tab_X, dev), seed=seed, step=T, rows=pl.node_range(), x_s=xs, want_onehot=False,

@@ -57,8 +57,9 @@ def _worker(rank, world, port, backend, name, q):
     dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     try:
         from graphmaker_amd.parallel import ShardPlan
+        name, _, variant = name.partition(":")
         cfg, model = _model(name, dev)
-        plan = ShardPlan.make(cfg["N"], world, rank)
+        plan = ShardPlan.make(cfg["N"], world, rank, replicate_graph_part=variant == "replicated")
         want = model.sample(seed=cfg["seed"])
         got = model.sample(seed=cfg["seed"], plan=plan)
         again = model.sample(seed=cfg["seed"], plan=plan)          # persistent gather buffers are reused correctly
@@ -168,7 +169,15 @@ def test_sharded_sample_ranks_share_one_gpu(world, name):
     _run(world, "gloo", name)
 
 
-@pytest.mark.parametrize("name", ["sync_mid", "async_mid"])
+@pytest.mark.parametrize("world,name", [(2, "sync_mid:replicated"), (3, "sync_small:replicated"), (2, "async_mid:replicated")])
+def test_sharded_sample_with_replicated_graph_part(world, name):
+    """ShardPlan(replicate_graph_part=True), the north-star layout (SURVEY.md 8e option 1): every rank runs input
+    projections and message passing on all N rows, only mlp_out is row-sharded; collectives = h + X + edge segments.
+    Bit-identical to the single-GPU sample, like the stage-sharded default."""
+    _run(world, "gloo", name)
+
+
+@pytest.mark.parametrize("name", ["sync_mid", "async_mid", "sync_mid:replicated"])
 def test_sharded_sample_one_rank_rccl(name):
     _run(1, "nccl", name)
 
