@@ -1,6 +1,7 @@
 """Tensor-level wrappers of the C ABI (include/graphmaker_hip.h).  Each function is one library call on torch's
 current stream; torch supplies device memory and nothing else."""
 import ctypes as C
+import weakref
 
 import torch
 
@@ -10,7 +11,11 @@ from ._lib import F32, I32, I64, U32, U64, ptr, require, stream_ptr, words_per_r
 
 # Index arguments that come from the caller (labels, pair lists) are range-checked on the host before a kernel indexes with
 # them: the reference's nn.Embedding / tensor indexing raise on a bad index, an unchecked kernel would read out of bounds.
-# One small reduction + host read per NEW tensor (identity and version are remembered); set to False to skip.
+# One fused min/max reduction + ONE host read per tensor OBJECT and version: the memo holds a weak reference to the tensor that
+# was checked, never its address (a fresh batch tensor that the caching allocator puts at the address of the previous one
+# is a different object and is checked again).  A training loop that builds new index tensors every step therefore pays one
+# device-to-host synchronisation per index argument and step; loops that cannot afford it validate their batches once
+# up front and set VALIDATE_INDICES = False.
 VALIDATE_INDICES = True
 _validated = {}
 
@@ -19,13 +24,13 @@ def check_index_range(t, hi, what):
     """Raise IndexError unless every entry of the integer tensor t lies in [0, hi)."""
     if not VALIDATE_INDICES or t.numel() == 0:
         return
-    key = (what, t.data_ptr(), t._version, t.numel(), int(hi))
-    if _validated.get(what) == key:
+    memo = _validated.get(what)
+    if memo is not None and memo[0]() is t and memo[1:] == (t._version, t.numel(), int(hi)):
         return
-    lo_v, hi_v = int(t.min().item()), int(t.max().item())
+    lo_v, hi_v = (int(v) for v in torch.stack(torch.aminmax(t)).tolist())
     if lo_v < 0 or hi_v >= hi:
         raise IndexError(f"{what}: values span [{lo_v}, {hi_v}], valid range is [0, {hi})")
-    _validated[what] = key
+    _validated[what] = (weakref.ref(t), t._version, t.numel(), int(hi))
 
 
 class Adjacency:

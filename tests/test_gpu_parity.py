@@ -886,6 +886,33 @@ def test_degenerate_sizes_whole_sample_bit_identical_to_oracle(dev, N, F, C, den
     assert X.shape == (F, N, 2) and Y1h.shape == (N, C) and E.shape == (N, N)
 
 
+def test_bad_pair_index_is_caught_on_a_fresh_tensor_at_a_recycled_address(dev):
+    """ops.check_index_range remembers which tensor OBJECT it has validated, not an address: a new batch tensor that the
+    caching allocator places where the previous (valid) one lived must be checked again (the reference's tensor indexing
+    raises on a bad index, model/gnn.py:246)."""
+    ops = _ops()
+    h = torch.randn(10, 128, device=dev)
+    src = torch.arange(0, 8, device=dev)
+    dst = torch.arange(1, 9, device=dev)
+    ops.hadamard_gather(h, src, dst)
+    ops.hadamard_gather(h, src, dst)                       # memoised: same objects, same versions
+    addr = src.data_ptr()
+    del src
+    held = []
+    for _ in range(256):                                   # same size and dtype: the allocator hands the block back
+        bad = torch.arange(3, 11, device=dev)
+        if bad.data_ptr() == addr:
+            break
+        held.append(bad)
+    else:
+        pytest.skip("the caching allocator did not recycle the block")
+    with pytest.raises(IndexError, match="src"):
+        ops.hadamard_gather(h, bad, dst)
+    dst[0] = -1                                            # in-place change of a validated tensor: its version moved
+    with pytest.raises(IndexError, match="dst"):
+        ops.hadamard_gather(h, torch.arange(0, 8, device=dev), dst)
+
+
 def test_no_fallback_on_cpu_tensors():
     from graphmaker_amd import ops
     from graphmaker_amd._lib import GraphMakerHipError

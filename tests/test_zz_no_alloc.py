@@ -25,11 +25,16 @@ def _prior_both(lib, n, p1, seed, dev, u=None):
     rc = lib.gm_prior_E(*args, C.c_void_p(upper.data_ptr()), C.c_void_p(want.data_ptr()), stream)
     assert rc == 0, lib.gm_last_error()
     torch.cuda.synchronize()
+    # "allocates nothing" at two levels: torch's caching allocator (which a ctypes call cannot touch anyway) and the
+    # driver's free-byte count, which a hipMalloc / hipMallocAsync inside the library WOULD move.  The gm_prior_E call above
+    # has already made the code object and its static scratch array resident.
     before = torch.cuda.memory_allocated(dev), torch.cuda.memory_reserved(dev)
+    free_before = torch.cuda.mem_get_info(dev)[0]
     rc = lib.gm_prior_E_static(*args, C.c_void_p(got.data_ptr()), stream)
     assert rc == 0, lib.gm_last_error()
     torch.cuda.synchronize()
     assert (torch.cuda.memory_allocated(dev), torch.cuda.memory_reserved(dev)) == before
+    assert torch.cuda.mem_get_info(dev)[0] >= free_before, "device memory was allocated inside gm_prior_E_static"
     return got, want
 
 
