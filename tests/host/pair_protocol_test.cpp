@@ -7,6 +7,7 @@
 // wait timed out again); (3) a launch that starts with the stall word set does nothing.
 // Build + run: tests/test_host_cpu.py (g++ -O2 -pthread).  Prints "ok" and exits 0, or says what failed.
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <thread>
@@ -24,14 +25,16 @@ struct Workgroup {
 };
 
 struct Wait {          // the policy bounded_wait() runs over: LdsWait of gm_pair_common.h with atomics for LDS words
-    std::atomic<int>* flags; int cnt, need; Workgroup* wg; long* polls; int* raised;
+    std::atomic<int>* flags; int cnt, need; Workgroup* wg; long* polls; int* raised; long* polls_paused;
     bool satisfied() { for (int k = 0; k < cnt; ++k) if (flags[k].load(std::memory_order_acquire) < need) { ++*polls; return false; } return true; }
     bool aborted() { return wg->abort.load() != 0; }
     void raise() { wg->abort = 1; wg->stall->fetch_or(1u); ++*raised; }
-    void pause() { std::this_thread::yield(); }
+    // a poll of the kernel costs ~0.1 us of a wave that nothing can deschedule; a host thread can lose its core for
+    // milliseconds, so the model's polls are made slower (2^18 of them: >= 0.4 s) -- the COUNT is what is checked
+    void pause() { if ((++*polls_paused & 63) == 0) std::this_thread::sleep_for(std::chrono::microseconds(100)); else std::this_thread::yield(); }
 };
 
-struct Result { long polls = 0; int raised = 0, items = 0; };
+struct Result { long polls = 0, paused = 0; int raised = 0, items = 0; };
 
 // wave `wv` of a workgroup that takes queue items until `nitems`; `lose_item` / `lose_wave`: that wave skips publishing
 // its last row-unit of that item (the lost hand-shake)
@@ -40,10 +43,10 @@ static void wave(Workgroup* wg, int wv, int nitems, int lose_item, int lose_wave
     int seq = 0, units_done = 0;
     int t = wg->stall->load() ? 0x7fffffff : 0;         // tile_s[0]: every wave reads the same first item
     while (t < nitems) {
-        Wait w0{wg->stg, 4, seq, wg, &res->polls, &res->raised};
+        Wait w0{wg->stg, 4, seq, wg, &res->polls, &res->raised, &res->paused};
         if (!bounded_wait(w0, WAIT_SPINS, true)) break;
         for (int u = 0; u < 8; ++u) {
-            Wait wt{&wg->turn[wv ^ 4], 1, units_done + grp, wg, &res->polls, &res->raised};
+            Wait wt{&wg->turn[wv ^ 4], 1, units_done + grp, wg, &res->polls, &res->raised, &res->paused};
             bounded_wait(wt, TURN_SPINS, false);
             ++units_done;
             if (!(seq == lose_item && wv == lose_wave && u == 7)) wg->turn[wv].store(units_done, std::memory_order_release);
@@ -51,11 +54,11 @@ static void wave(Workgroup* wg, int wv, int nitems, int lose_item, int lose_wave
         ++res->items;
         ++seq;
         if (wv == 0) wg->pub.store(seq, std::memory_order_release);
-        Wait w1{&wg->pub, 1, seq, wg, &res->polls, &res->raised};
+        Wait w1{&wg->pub, 1, seq, wg, &res->polls, &res->raised, &res->paused};
         if (!bounded_wait(w1, WAIT_SPINS, true)) break;
         t = wg->stall->load() ? 0x7fffffff : seq;
         if (grp == 0 && t < nitems) {
-            Wait w2{wg->turn, 8, units_done, wg, &res->polls, &res->raised};
+            Wait w2{wg->turn, 8, units_done, wg, &res->polls, &res->raised, &res->paused};
             if (!bounded_wait(w2, WAIT_SPINS, true)) break;
             wg->stg[wv].store(seq, std::memory_order_release);
         }
