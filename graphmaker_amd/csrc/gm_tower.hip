@@ -30,17 +30,23 @@ extern "C" int gm_device_cus(int* cus) {
 }
 
 static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+// Row stride of h_cat in the workspace: the width rounded up to 32 floats, so that every row starts on a 128-byte line.
+// The mean aggregation gathers 128-byte pieces of [h_X | h_Y] rows straight out of h_cat; with the natural stride of the
+// ht = 16 configurations (1744 floats = 54.5 lines) every other row's pieces straddled two lines and the d = 576 launch
+// fetched 125 MB across the L2 boundary instead of 79 MB (tools/spmm_traffic.py, profiles/r3_spmm_traffic.txt).
+static inline int64_t hcat_stride(int64_t Hc) { return (Hc + 31) & ~(int64_t)31; }
 
 struct TowerWs {
     size_t hcat, agg, mid, tmpX, ht0, ht1, xu8, x01, total;
 };
 static TowerWs tower_layout(const gm_tower_dims* d, int64_t n) {
     const int64_t Hc = (int64_t)(d->num_layers + 1) * (d->hidden_X + d->hidden_Y) + d->hidden_t;
+    const int64_t ldc = hcat_stride(Hc);
     const int64_t ka = d->hidden_X + d->hidden_Y + d->hidden_t;
     TowerWs w;
     size_t off = 0;
-    w.hcat = off; off += align_up(sizeof(float) * (size_t)(n * Hc));
-    w.agg = off;  off += align_up(sizeof(float) * (size_t)(n * ka));
+    w.hcat = off; off += align_up(sizeof(float) * (size_t)(n * ldc));
+    w.agg = off;  off += align_up(sizeof(float) * (size_t)(n * hcat_stride(ka)));   // rows on 128-byte lines, like hcat
     w.mid = off;  off += align_up(sizeof(float) * (size_t)(n * Hc));
     w.tmpX = off; off += align_up(sizeof(float) * (size_t)(n * d->hidden_X));
     w.ht0 = off;  off += align_up(sizeof(float) * (size_t)d->hidden_t);
@@ -85,7 +91,7 @@ struct TowerCtx {
     float *hcat, *agg, *mid, *tmpX, *ht0, *ht1, *x01;
     uint8_t* xu8;
     int ht, hX, hY, nl;
-    int64_t Hc, ka, offY, offT;
+    int64_t Hc, ldc, ka, lda, offY, offT;   // ldc / lda: row strides of hcat / agg (>= Hc / ka, hcat_stride)
 };
 
 int tower_ctx(TowerCtx& c, const gm_tower_dims* d, const float* const* P, int64_t n, void* workspace, size_t workspace_bytes,
@@ -109,7 +115,9 @@ int tower_ctx(TowerCtx& c, const gm_tower_dims* d, const float* const* P, int64_
     c.x01 = reinterpret_cast<float*>(ws + L.x01);
     c.ht = d->hidden_t; c.hX = d->hidden_X; c.hY = d->hidden_Y; c.nl = d->num_layers;
     c.Hc = (int64_t)(c.nl + 1) * (c.hX + c.hY) + c.ht;
+    c.ldc = hcat_stride(c.Hc);
     c.ka = c.hX + c.hY + c.ht;
+    c.lda = hcat_stride(c.ka);
     c.offY = (int64_t)(c.nl + 1) * c.hX;
     c.offT = (int64_t)(c.nl + 1) * (c.hX + c.hY);
     return GM_OK;
@@ -123,13 +131,13 @@ int tower_input(const TowerCtx& c, const float* t_float, const float* X_one_hot,
     if (rows <= 0) return GM_OK;
     const int64_t in_X = c.d->in_X;
     if (c.ht <= 256) {   // one launch: both layers of mlp_in_t and the two broadcasts of h_t
-        GM_TRY(launch_time_embed(c.ht, t_float, P[0], P[1], P[2], P[3], rows, c.hcat + r0 * c.Hc + c.offT, c.Hc,
-                                 c.agg + r0 * c.ka + c.hX + c.hY, c.ka, c.s));
+        GM_TRY(launch_time_embed(c.ht, t_float, P[0], P[1], P[2], P[3], rows, c.hcat + r0 * c.ldc + c.offT, c.ldc,
+                                 c.agg + r0 * c.lda + c.hX + c.hY, c.lda, c.s));
     } else {
         GM_TRY(gm_linear(1, c.ht, 1, t_float, 1, P[0], 1, P[1], c.ht0, c.ht, 1, c.stream));
         GM_TRY(gm_linear(1, c.ht, c.ht, c.ht0, c.ht, P[2], c.ht, P[3], c.ht1, c.ht, 1, c.stream));
-        GM_TRY(launch_broadcast_row(rows, c.ht, c.ht1, c.hcat + r0 * c.Hc + c.offT, c.Hc, c.s));
-        GM_TRY(launch_broadcast_row(rows, c.ht, c.ht1, c.agg + r0 * c.ka + c.hX + c.hY, c.ka, c.s));
+        GM_TRY(launch_broadcast_row(rows, c.ht, c.ht1, c.hcat + r0 * c.ldc + c.offT, c.ldc, c.s));
+        GM_TRY(launch_broadcast_row(rows, c.ht, c.ht1, c.agg + r0 * c.lda + c.hX + c.hY, c.lda, c.s));
     }
     if (X_one_hot || x_u8) {   // both NULL: h_X^0 of these rows is still in the workspace from the previous call with the same X
         // first layer on the attributes themselves (gm_onehot.hip): a one-hot input is reduced to them first
@@ -143,9 +151,9 @@ int tower_input(const TowerCtx& c, const float* t_float, const float* X_one_hot,
         const bool walk = sparse_X && c.hX % 4 == 0 && c.hX <= 2048 && F < 65536;
         GM_TRY(gm_onehot_linear(rows, F, c.hX, x_u8 + r0 * F, prep, walk ? nullptr : c.x01 + r0 * ldF, c.tmpX + r0 * c.hX, c.hX, 1,
                                 c.stream));
-        GM_TRY(gm_linear(rows, c.hX, c.hX, c.tmpX + r0 * c.hX, c.hX, P[6], c.hX, P[7], c.hcat + r0 * c.Hc, c.Hc, 1, c.stream));
+        GM_TRY(gm_linear(rows, c.hX, c.hX, c.tmpX + r0 * c.hX, c.hX, P[6], c.hX, P[7], c.hcat + r0 * c.ldc, c.ldc, 1, c.stream));
     }
-    GM_TRY(launch_gather_rows(rows, c.hY, Y + r0, P[8], c.hY, c.hcat + r0 * c.Hc + c.offY, c.Hc, c.s));
+    GM_TRY(launch_gather_rows(rows, c.hY, Y + r0, P[8], c.hY, c.hcat + r0 * c.ldc + c.offY, c.ldc, c.s));
     return GM_OK;
 }
 
@@ -157,26 +165,26 @@ int tower_layer(const TowerCtx& c, int l, const int32_t* rowptr, const int32_t* 
     const float* const* Q = c.P + 9 + 8 * l;
     const float* hXl = src ? src : c.hcat + (int64_t)l * c.hX;
     const float* hYl = src ? src + c.hX : c.hcat + c.offY + (int64_t)l * c.hY;
-    const int64_t ld = src ? (int64_t)(c.hX + c.hY) : c.Hc;
-    float* agg = c.agg + r0 * c.ka;
+    const int64_t ld = src ? (int64_t)(c.hX + c.hY) : c.ldc;
+    float* agg = c.agg + r0 * c.lda;
     if (!c.d->is_mlp) {
         // GNNLayer.forward (:60-61): A @ [h_X | h_Y]; A @ h_Y is its last hY columns
         if (src) {   // gathered buffer: [h_X | h_Y] is one contiguous row, one launch covers both products
-            GM_TRY(launch_spmm_mean_rows(rows, c.n, rowptr + r0, colidx, src, ld, c.hX + c.hY, agg, c.ka, c.s));
+            GM_TRY(launch_spmm_mean_rows(rows, c.n, rowptr + r0, colidx, src, ld, c.hX + c.hY, agg, c.lda, c.s));
         } else {
-            GM_TRY(launch_spmm_mean_two(rows, rowptr + r0, colidx, hXl, c.hX, hYl, c.hY, ld, agg, c.ka, c.s));   // one launch
+            GM_TRY(launch_spmm_mean_two(rows, rowptr + r0, colidx, hXl, c.hX, hYl, c.hY, ld, agg, c.lda, c.s));   // one launch
         }
     } else {
         // MLPLayer.forward (:387-392): no aggregation, row-local
-        GM_TRY(launch_copy2d(rows, c.hX, c.hcat + r0 * c.Hc + (int64_t)l * c.hX, c.Hc, agg, c.ka, c.s));
-        GM_TRY(launch_copy2d(rows, c.hY, c.hcat + r0 * c.Hc + c.offY + (int64_t)l * c.hY, c.Hc, agg + c.hX, c.ka, c.s));
+        GM_TRY(launch_copy2d(rows, c.hX, c.hcat + r0 * c.ldc + (int64_t)l * c.hX, c.ldc, agg, c.lda, c.s));
+        GM_TRY(launch_copy2d(rows, c.hY, c.hcat + r0 * c.ldc + c.offY + (int64_t)l * c.hY, c.ldc, agg + c.hX, c.lda, c.s));
     }
-    float* hXn = c.hcat + r0 * c.Hc + (int64_t)(l + 1) * c.hX;
-    float* hYn = c.hcat + r0 * c.Hc + c.offY + (int64_t)(l + 1) * c.hY;
-    GM_TRY(gm_linear(rows, c.hX, c.ka, agg, c.ka, Q[0], c.ka, Q[1], hXn, c.Hc, 1, c.stream));        // update_X (:27-32,67)
-    GM_TRY(gm_layernorm(rows, c.hX, hXn, c.Hc, Q[2], Q[3], 1e-5f, c.stream));
-    GM_TRY(gm_linear(rows, c.hY, c.hY, agg + c.hX, c.ka, Q[4], c.hY, Q[5], hYn, c.Hc, 1, c.stream));  // update_Y (:33-38,68)
-    GM_TRY(gm_layernorm(rows, c.hY, hYn, c.Hc, Q[6], Q[7], 1e-5f, c.stream));
+    float* hXn = c.hcat + r0 * c.ldc + (int64_t)(l + 1) * c.hX;
+    float* hYn = c.hcat + r0 * c.ldc + c.offY + (int64_t)(l + 1) * c.hY;
+    GM_TRY(gm_linear(rows, c.hX, c.ka, agg, c.lda, Q[0], c.ka, Q[1], hXn, c.ldc, 1, c.stream));        // update_X (:27-32,67)
+    GM_TRY(gm_layernorm(rows, c.hX, hXn, c.ldc, Q[2], Q[3], 1e-5f, c.stream));
+    GM_TRY(gm_linear(rows, c.hY, c.hY, agg + c.hX, c.lda, Q[4], c.hY, Q[5], hYn, c.ldc, 1, c.stream));  // update_Y (:33-38,68)
+    GM_TRY(gm_layernorm(rows, c.hY, hYn, c.ldc, Q[6], Q[7], 1e-5f, c.stream));
     return GM_OK;
 }
 
@@ -186,7 +194,7 @@ int tower_output(const TowerCtx& c, float* out, int64_t r0, int64_t r1) {
     if (rows <= 0) return GM_OK;
     const float* const* O = c.P + 9 + 8 * c.nl;
     const int64_t os = c.d->out_size;
-    GM_TRY(gm_linear(rows, c.Hc, c.Hc, c.hcat + r0 * c.Hc, c.Hc, O[0], c.Hc, O[1], c.mid + r0 * c.Hc, c.Hc, 1, c.stream));
+    GM_TRY(gm_linear(rows, c.Hc, c.Hc, c.hcat + r0 * c.ldc, c.ldc, O[0], c.Hc, O[1], c.mid + r0 * c.Hc, c.Hc, 1, c.stream));
     GM_TRY(gm_linear(rows, os, c.Hc, c.mid + r0 * c.Hc, c.Hc, O[2], c.Hc, O[3], out + r0 * os, os, 0, c.stream));
     return GM_OK;
 }
@@ -218,7 +226,9 @@ extern "C" int gm_tower_forward(const gm_tower_dims* d, const float* const* P, i
     GM_TRY(tower_input(c, t_float, X_one_hot, x_u8, prep, sparse_X, Y, 0, n));
     for (int l = 0; l < c.nl; ++l) GM_TRY(tower_layer(c, l, rowptr, colidx, nullptr, 0, n));
     GM_TRY(tower_output(c, out, out_row_begin, out_row_end));
-    if (hcat_out) GM_HIP(hipMemcpyAsync(hcat_out, c.hcat, sizeof(float) * (size_t)(n * c.Hc), hipMemcpyDeviceToDevice, c.s));
+    if (hcat_out)
+        GM_HIP(hipMemcpy2DAsync(hcat_out, sizeof(float) * (size_t)c.Hc, c.hcat, sizeof(float) * (size_t)c.ldc,
+                                sizeof(float) * (size_t)c.Hc, (size_t)n, hipMemcpyDeviceToDevice, c.s));
     return GM_OK;
 }
 
@@ -246,8 +256,8 @@ extern "C" int gm_tower_stage(const gm_tower_dims* d, const float* const* P, int
     if (layer_dst && stage < c.nl && row_end > row_begin) {
         const int sl = stage + 1;
         const int64_t rows = row_end - row_begin, w = c.hX + c.hY;
-        GM_TRY(launch_copy2d(rows, c.hX, c.hcat + row_begin * c.Hc + (int64_t)sl * c.hX, c.Hc, layer_dst + row_begin * w, w, c.s));
-        GM_TRY(launch_copy2d(rows, c.hY, c.hcat + row_begin * c.Hc + c.offY + (int64_t)sl * c.hY, c.Hc,
+        GM_TRY(launch_copy2d(rows, c.hX, c.hcat + row_begin * c.ldc + (int64_t)sl * c.hX, c.ldc, layer_dst + row_begin * w, w, c.s));
+        GM_TRY(launch_copy2d(rows, c.hY, c.hcat + row_begin * c.ldc + c.offY + (int64_t)sl * c.hY, c.ldc,
                              layer_dst + row_begin * w + c.hX, w, c.s));
     }
     return GM_OK;
