@@ -3,8 +3,8 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/trace_cora
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 200 rocprofv3 --kernel-trace --output-format rocpd -d $OUT -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --workload cora_shape > $OUT/log.txt 2>&1 || { tail -20 $OUT/log.txt; exit 1; }
+timeout -s KILL 200 rocprofv3 --kernel-trace --output-format rocpd -d $OUT -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --workload ${WL:-cora_shape} > $OUT/log.txt 2>&1 || { tail -20 $OUT/log.txt; exit 1; }
 DB=$(find $OUT -name "*.db" | head -1)
 echo DB=$DB
-python3 $R/tools/trace_step.py $DB > $R/gpurun_out/trace_cora_step.txt 2>&1 || tail -5 $R/gpurun_out/trace_cora_step.txt
+python3 $R/tools/trace_step.py $DB > $R/gpurun_out/trace_${WL:-cora_shape}_step.txt 2>&1 || tail -5 $R/gpurun_out/trace_${WL:-cora_shape}_step.txt
 rm -rf $OUT
