@@ -407,7 +407,7 @@ def main():
     # HBM bytes per launch of the pair kernel: PMC counters cannot be read from inside this process, so the figure is the
     # one the committed rocprofv3 --pmc passes of this same command produced (tools/profile_bench.sh); its file is named
     traffic, traffic_source = None, None
-    for cand in ("r2_pmc_summary.json", "r1_pmc_summary.json"):
+    for cand in ("r3_pmc_summary.json", "r2_pmc_summary.json", "r1_pmc_summary.json"):
         try:
             with open(os.path.join(ROOT, "profiles", cand)) as fh:
                 if world == 1 and wl["name"] == "amazon_computer":
