@@ -11,26 +11,31 @@ from ._lib import F32, I32, I64, U32, U64, ptr, require, stream_ptr, words_per_r
 
 # Index arguments that come from the caller (labels, pair lists) are range-checked on the host before a kernel indexes with
 # them: the reference's nn.Embedding / tensor indexing raise on a bad index, an unchecked kernel would read out of bounds.
-# One fused min/max reduction + ONE host read per tensor OBJECT and version: the memo holds a weak reference to the tensor that
-# was checked, never its address (a fresh batch tensor that the caching allocator puts at the address of the previous one
+# One fused min/max reduction + ONE host read per tensor OBJECT and version: the memo is keyed on the tensor object (weakly),
+# never on its address (a fresh batch tensor that the caching allocator puts at the address of the previous one
 # is a different object and is checked again).  A training loop that builds new index tensors every step therefore pays one
 # device-to-host synchronisation per index argument and step; loops that cannot afford it validate their batches once
 # up front and set VALIDATE_INDICES = False.
 VALIDATE_INDICES = True
-_validated = {}
+_validated = {}       # id(tensor) -> (weak reference to that tensor, {(what, hi): version}); an entry dies with its tensor
 
 
 def check_index_range(t, hi, what):
     """Raise IndexError unless every entry of the integer tensor t lies in [0, hi)."""
     if not VALIDATE_INDICES or t.numel() == 0:
         return
-    memo = _validated.get(what)
-    if memo is not None and memo[0]() is t and memo[1:] == (t._version, t.numel(), int(hi)):
+    entry = _validated.get(id(t))
+    if entry is not None and entry[0]() is not t:          # the id was recycled before the old tensor's callback ran
+        entry = None
+    if entry is not None and entry[1].get((what, int(hi))) == t._version:
         return
     lo_v, hi_v = (int(v) for v in torch.stack(torch.aminmax(t)).tolist())
     if lo_v < 0 or hi_v >= hi:
         raise IndexError(f"{what}: values span [{lo_v}, {hi_v}], valid range is [0, {hi})")
-    _validated[what] = (weakref.ref(t), t._version, t.numel(), int(hi))
+    if entry is None:
+        key = id(t)
+        entry = _validated[key] = (weakref.ref(t, lambda _r, k=key: _validated.pop(k, None)), {})
+    entry[1][(what, int(hi))] = t._version
 
 
 class Adjacency:

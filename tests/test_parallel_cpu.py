@@ -107,3 +107,32 @@ def test_sharded_step_reassembles_exactly(world, name):
     assert sorted(r[0] for r in res) == list(range(world))
     for rank, ok_h, ok_e, ok_x in res:
         assert ok_h and ok_e and ok_x, f"rank {rank}: h={ok_h} E={ok_e} X={ok_x}"
+
+
+@pytest.mark.parametrize("n", [2, 67, 200, 2708, 7650, 13752, 100000])
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+def test_shard_plan_partitions_rows_pairs_and_nodes(n, world):
+    """Host logic of the decomposition: the folded pair chunks of all ranks cover every row of the pair matrix exactly once and
+    all P pairs, the node blocks partition the nodes, the padded row count covers n, every rank computes the same segment
+    capacity, and the two tower splits differ only in which adjacency rows a rank builds."""
+    from graphmaker_amd.parallel import ShardPlan, edge_segment_capacity
+    plans = [ShardPlan.make(n, world, r) for r in range(world)]
+    rows = np.zeros(n, np.int32)
+    nodes = np.zeros(n, np.int32)
+    for pl in plans:
+        assert pl.chunk_rows % 64 == 0 and pl.padded_pair_rows >= n
+        for b, e in pl.pair_chunks():
+            assert 0 <= b <= e <= n and (b % 64 == 0 or b == e)
+            rows[b:e] += 1
+        b, e = pl.node_range()
+        nodes[b:e] += 1
+        assert pl.adjacency_rows() == pl.node_range()
+        rep = ShardPlan.make(n, world, pl.rank, replicate_graph_part=True)
+        assert rep.adjacency_rows() is None and rep.pair_chunks() == pl.pair_chunks() and rep.node_range() == pl.node_range()
+    assert (rows == 1).all() and (nodes == 1).all()
+    assert sum(pl.pairs_of(pl.rank) for pl in plans) == n * (n - 1) // 2
+    caps = {edge_segment_capacity(pl, 2.6e-3) for pl in plans}
+    assert len(caps) == 1 and min(caps) >= 1
+    if world > 1 and n >= 2708:          # equal pairs per rank to within the rounding of a chunk to 64 rows (the point of the fold):
+        per = [pl.pairs_of(pl.rank) for pl in plans]       # 1.3 % at amazon_computer / 8 ranks, 9 % at Cora / 8 ranks (192-row chunks)
+        assert max(per) <= (1.05 if n >= 7650 else 1.10) * (sum(per) / world)
