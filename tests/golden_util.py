@@ -189,6 +189,17 @@ def train_batch(cfg, B=1500):
     return iu[pick].astype(np.int64), ju[pick].astype(np.int64)       # dst = row index, src = column index
 
 
+LARGE_TRAIN_BATCH = 16384      # configs/cora/train_Sync.yaml:42
+
+
+def grad_sample_index(cfg, key, numel, k=2048):
+    """The fixed positions of a parameter gradient a large training fixture keeps (all of a tensor of at most k entries)."""
+    if numel <= k:
+        return np.arange(numel)
+    rs = np.random.RandomState((cfg["seed"] + 5000 + sum(map(ord, key))) % (2 ** 31))
+    return np.sort(rs.choice(numel, size=k, replace=False))
+
+
 def train_uniforms(cfg, kind, t):
     """Host-supplied uniforms (24-bit grid) of the forward-noising draws: kind "E" -> (N*N,), "X" -> (F*N,)."""
     rs = np.random.RandomState(cfg["seed"] + 4000 + 17 * t + (0 if kind == "E" else 7))

@@ -335,13 +335,13 @@ def _model(cfg, dev, train=True):
     return model.train() if train else model.eval()
 
 
-def _data(cfg, dev):
+def _data(cfg, dev, B=1500):
     x0, Y, E0 = gu.real_graph(cfg)
     N = cfg["N"]
     X3 = F.one_hot(torch.from_numpy(x0.T.astype(np.int64)), 2).float().to(dev)
     X2 = torch.transpose(X3, 0, 1).reshape(N, -1).contiguous()
     E1h = F.one_hot(torch.from_numpy(E0), 2).float().to(dev)
-    bdst, bsrc = (torch.from_numpy(a).to(dev) for a in gu.train_batch(cfg))
+    bdst, bsrc = (torch.from_numpy(a).to(dev) for a in gu.train_batch(cfg, B=B))
     return dict(x0=x0, Y=torch.from_numpy(Y).to(dev), E0=E0, X3=X3, X2=X2, E1h=E1h, bdst=bdst, bsrc=bsrc,
                 bE=E1h[bdst, bsrc])
 
@@ -444,6 +444,43 @@ def test_log_p_t_losses_and_gradients_match_reference(dev, name):
                 assert np.linalg.norm(got - ref) <= 2e-5 * nrm + 1e-9, f"grad {pre}.{k}: rel err {np.linalg.norm(got - ref) / nrm:.2e}"
             checked += 1
     assert checked == sum(1 for _ in model.graph_encoder.parameters())
+
+
+def test_cora_size_training_step_matches_reference(dev):
+    """BASELINE.json configs[0] shape on the training path: the reference's own log_p_t at every t,
+    autograd backward at t = T-1 and val_step at N=2708, F=1433 with the hidden sizes and batch size of
+    configs/cora/train_Sync.yaml (fixture train_cora_sync, tools/gen_golden_train.py).  Losses and validation terms rtol 1e-5;
+    of every parameter gradient the L2 norm (rel 2e-5) and 2048 fixed entries (2e-6 + 2e-4 |ref|)."""
+    cfg = gu.LARGE_CASES["cora_sync"]
+    gold = _load_train("cora_sync")
+    model, d = _model(cfg, dev), _data(cfg, dev, B=gu.LARGE_TRAIN_BATCH)
+    for t, (lX_ref, lE_ref) in enumerate(gold["losses"]):
+        lX, lE = _log_p_t(model, cfg, d, t, dev)
+        assert abs(lX.item() - lX_ref) <= 1e-5 * abs(lX_ref), (t, lX.item(), lX_ref)
+        assert abs(lE.item() - lE_ref) <= 1e-5 * abs(lE_ref), (t, lE.item(), lE_ref)
+    t = int(gold["grad_t"][0])
+    model.zero_grad()
+    lX, lE = _log_p_t(model, cfg, d, t, dev)
+    (lX + lE).backward()
+    checked = 0
+    for pre, mod in (("X", model.graph_encoder.pred_X), ("E", model.graph_encoder.pred_E)):
+        for k, p in mod.named_parameters():
+            got = p.grad.cpu().numpy().astype(np.float64).reshape(-1)
+            idx = gu.grad_sample_index(cfg, f"{pre}.{k}", got.size)
+            _close(got[idx], gold[f"gsamp_{pre}.{k}"], 2e-6, 2e-4, f"grad {pre}.{k} (sampled entries)")
+            nrm = float(gold[f"gnorm_{pre}.{k}"][0])
+            assert abs(np.linalg.norm(got) - nrm) <= 2e-5 * nrm + 1e-9, f"grad {pre}.{k}: norm {np.linalg.norm(got):.6e} vs {nrm:.6e}"
+            checked += 1
+    assert checked == sum(1 for _ in model.graph_encoder.parameters())
+    model = model.eval()
+    nE, nX = model._noise_E, model._noise_X
+    model._noise_E = lambda bits0, ab, seed, step, u=None: nE(bits0, ab, seed, step,
+                                                              u=torch.from_numpy(gu.train_uniforms(cfg, "E", step)).to(dev))
+    model._noise_X = lambda x0, ab, seed, step, u=None: nX(x0, ab, seed, step,
+                                                           u=torch.from_numpy(gu.train_uniforms(cfg, "X", step)).to(dev))
+    v = model.val_step(d["X3"], d["E1h"], d["Y"], d["bsrc"], d["bdst"], d["bE"])
+    for got, ref, what in zip(v, gold["val_step"], ("denoise_match_E", "denoise_match_X", "log_p_0_E", "log_p_0_X")):
+        assert abs(got - ref) <= 1e-5 * abs(ref) + 1e-9, (what, got, ref)
 
 
 @pytest.mark.parametrize("name", gu.TRAIN_CASES)

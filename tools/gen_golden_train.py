@@ -139,6 +139,57 @@ def run_case(name, diffusion):
     print(f"{name}: wrote {path} ({os.path.getsize(path) / 1e3:.0f} kB) losses={losses} val={v}")
 
 
+def run_large_case(name, diffusion):
+    """A BASELINE.json-sized training step (gu.LARGE_CASES, Sync): the reference's log_p_t at every t, autograd backward at
+    t = T-1 and val_step at N=2708, F=1433 with the yaml's hidden sizes and batch size (configs/cora/train_Sync.yaml:42).
+    Stored: the losses, the validation terms, and of every parameter gradient its L2 norm and the values at 2048 fixed
+    positions (golden_util.grad_sample_index) -- the full gradients are 80 MB."""
+    cfg = dict(gu.LARGE_CASES[name])
+    Ctx.cfg = cfg
+    N, F = cfg["N"], cfg["F"]
+    model = build(cfg, diffusion)
+    model.train()
+    x0, Y, E0 = gu.real_graph(cfg)
+    X3 = F_.one_hot(torch.from_numpy(x0.T.astype(np.int64)), 2).float()
+    E1h = F_.one_hot(torch.from_numpy(E0), 2).float()
+    Yt = torch.from_numpy(Y)
+    bdst, bsrc = (torch.from_numpy(a) for a in gu.train_batch(cfg, B=gu.LARGE_TRAIN_BATCH))
+    bE = E1h[bdst, bsrc]
+    out = {}
+    orig = model.apply_noise
+
+    def apply_noise(X, E, t=None):
+        Ctx.t_E = Ctx.t_X = int(t.item())
+        return orig(X, E, t)
+    model.apply_noise = apply_noise
+    saved = torch.Tensor.multinomial
+    torch.Tensor.multinomial = _shim_multinomial
+    try:
+        losses = []
+        T = cfg["T"]
+        for t in range(T + 1):
+            model.zero_grad()
+            lX, lE = model.log_p_t(X3, E1h, Yt, bsrc, bdst, bE, torch.LongTensor([t]))
+            losses.append([lX.item(), lE.item()])
+            if t == T - 1:
+                (lX + lE).backward()
+                out["grad_t"] = np.array([t], np.int32)
+                for pre, mod in (("X", model.graph_encoder.pred_X), ("E", model.graph_encoder.pred_E)):
+                    for k, p in mod.named_parameters():
+                        g = p.grad.detach().numpy().astype(np.float64).reshape(-1)
+                        out[f"gnorm_{pre}.{k}"] = np.array([np.linalg.norm(g)])
+                        out[f"gsamp_{pre}.{k}"] = g[gu.grad_sample_index(cfg, f"{pre}.{k}", g.size)].astype(np.float32)
+        out["losses"] = np.array(losses, np.float64)
+        model.eval()
+        v = model.val_step(X3, E1h, Yt, bsrc, bdst, bE)
+        out["val_step"] = np.array(v, np.float64)
+    finally:
+        torch.Tensor.multinomial = saved
+    path = os.path.join(gu.GOLDEN_DIR, f"train_{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: wrote {path} ({os.path.getsize(path) / 1e3:.0f} kB) losses={losses} val={v}")
+
+
 def run_preprocess(name):
     """The reference's data.py preprocess() on the synthetic real graph (a stand-in object with the three DGLGraph
     members it touches: ndata, num_nodes(), edges()); `dgl` / `dgl.data` are empty stand-in modules for the imports."""
@@ -175,9 +226,14 @@ def run_preprocess(name):
 
 def main():
     gnn, diffusion = gg.load_reference()
-    run_preprocess("sync_small")
-    for name in (sys.argv[1:] or gu.TRAIN_CASES):
-        run_case(name, diffusion)
+    names = sys.argv[1:] or gu.TRAIN_CASES
+    if not sys.argv[1:]:
+        run_preprocess("sync_small")
+    for name in names:
+        if name in gu.LARGE_CASES:
+            run_large_case(name, diffusion)
+        else:
+            run_case(name, diffusion)
 
 
 if __name__ == "__main__":
