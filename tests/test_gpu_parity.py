@@ -913,6 +913,50 @@ def test_bad_pair_index_is_caught_on_a_fresh_tensor_at_a_recycled_address(dev):
         ops.hadamard_gather(h, torch.arange(0, 8, device=dev), dst)
 
 
+def test_structure_step_can_be_captured_in_a_hip_graph_and_replayed(dev):
+    """Every entry point only enqueues on the caller's stream and allocates nothing, so a sequence of them is legal under HIP
+    stream capture: one whole structure step (CSR build, edge tower, all-pairs kernel incl. its counter memset, symmetrise)
+    is captured once with torch.cuda.CUDAGraph and replayed; every replay must give the eager result bit for bit (the
+    Philox key is a kernel argument, so a replay repeats the captured draw)."""
+    ops = _ops()
+    cfg, g, model, *_ = _models("sync_mid", dev)
+    N, T, seed = cfg["N"], cfg["T"], cfg["seed"]
+    Y32 = t_(g["Y"], dev)
+    bits_in = bits_t(_bits_from_nz(g[f"e{T}_E_in_nz"], N)[0], dev)
+    oh = t_(orc.onehot_from_x(g[f"e{T}_X_in"]), dev)
+    tab_E, _ = model.step_tables(T)
+    t_float = torch.tensor([1.0], dtype=torch.float32, device=dev)
+    pred_E = model.graph_encoder.pred_E
+    W1, b1, W2, b2 = pred_E.pair_params()
+
+    def step(ws_csr, ws_pair, upper, out_sym):
+        A_t = ops.adjacency_from_bitmap(bits_in, N, workspace=ws_csr)
+        h = pred_E.gnn_encoder._run(t_float, oh, Y32, A_t)
+        ops.pair_score_sample(h, W1, b1, W2, b2, bits_in, tab_E, seed=seed, step=T, out_upper=upper, workspace=ws_pair)
+        return ops.symmetrize_upper(upper, N, out=out_sym)
+
+    ws_csr, ws_pair = ops.CsrWorkspace(N, dev), ops.pair_workspace(dev)
+    upper, sym = torch.zeros_like(bits_in), torch.empty_like(bits_in)
+    want = step(ws_csr, ws_pair, upper, sym).clone()               # eager (also warms every lazily built buffer)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        step(ws_csr, ws_pair, upper, sym)
+        with torch.cuda.graph(graph, stream=side):
+            step(ws_csr, ws_pair, upper, sym)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    for _ in range(3):
+        sym.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(sym, want)
+    ops.check_pair_workspace(ws_pair)
+    ws_csr.check()
+    assert int(want.ne(0).sum()) > 0
+
+
 def test_no_fallback_on_cpu_tensors():
     from graphmaker_amd import ops
     from graphmaker_amd._lib import GraphMakerHipError
