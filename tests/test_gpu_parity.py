@@ -1227,9 +1227,9 @@ def test_amazon_size_whole_sync_sample_bit_identical_to_oracle(dev, n, F, C, den
 
 def test_amazon_computer_async_trajectory_against_the_oracle(dev):
     """configs/amazon_computer/train_Async.yaml (MLPTower hidden_X=1024, T_X=7, T_E=9) at N=13752, F=767: the whole attribute
-    chain (7 steps, model/diffusion.py:1330-1358), the E prior, and the first 3 of the 9 structure steps (:1379-1401, each
-    on the final attributes and the previous step's sampled graph), free-running; the state after every step equals the
-    oracle's bit for bit."""
+    chain (7 steps, model/diffusion.py:1330-1358), the E prior, and all 9 structure steps (:1379-1401, each on the final
+    attributes and the previous step's sampled graph), free-running; the state after every step equals the oracle's bit
+    for bit (30 s, most of it the CPU oracle's nine passes over 94.5 M pairs)."""
     import graphmaker_amd as gm
     ops = _ops()
     n, F, C = 13752, 767, 10
@@ -1258,7 +1258,7 @@ def test_amazon_computer_async_trajectory_against_the_oracle(dev):
     bits = ops.prior_E(n, float(Em[0]), float(Em[1]), dev, seed=seed)
     bo = orc.prior_E(n, Em, seed=seed)
     oh_o = orc.onehot_from_x(xo)
-    for t in range(9, 6, -1):
+    for t in range(9, 0, -1):
         bits = model.structure_step(t, oh, Y32, bits, seed, reuse_X=t != 9)
         rp, ci = orc.csr_from_bitmap(bo, n)
         h = towerE.forward(np.float32(t / 9), oh_o, y, rp, ci)
