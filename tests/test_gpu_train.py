@@ -446,13 +446,15 @@ def test_log_p_t_losses_and_gradients_match_reference(dev, name):
     assert checked == sum(1 for _ in model.graph_encoder.parameters())
 
 
-def test_cora_size_training_step_matches_reference(dev):
-    """BASELINE.json configs[0] shape on the training path: the reference's own log_p_t at every t,
-    autograd backward at t = T-1 and val_step at N=2708, F=1433 with the hidden sizes and batch size of
-    configs/cora/train_Sync.yaml (fixture train_cora_sync, tools/gen_golden_train.py).  Losses and validation terms rtol 1e-5;
-    of every parameter gradient the L2 norm (rel 2e-5) and 2048 fixed entries (2e-6 + 2e-4 |ref|)."""
-    cfg = gu.LARGE_CASES["cora_sync"]
-    gold = _load_train("cora_sync")
+@pytest.mark.parametrize("name", ["cora_sync", "cora_async"])
+def test_cora_size_training_step_matches_reference(dev, name):
+    """BASELINE.json configs[0] / [1] shape on the training path: the reference's own log_p_t at every
+    t, autograd backward at the last interior t and val_step at N=2708, F=1433 with the hidden sizes and batch size of
+    configs/cora/train_{Sync,Async}.yaml (fixtures train_cora_sync / train_cora_async, tools/gen_golden_train.py; the
+    reference's own run-to-run spread on these gradients is 4e-7).  Losses and validation terms rtol 1e-5; of every parameter
+    gradient the L2 norm (rel 2e-5) and 2048 fixed entries (2e-6 + 2e-4 |ref|)."""
+    cfg = gu.LARGE_CASES[name]
+    gold = _load_train(name)
     model, d = _model(cfg, dev), _data(cfg, dev, B=gu.LARGE_TRAIN_BATCH)
     for t, (lX_ref, lE_ref) in enumerate(gold["losses"]):
         lX, lE = _log_p_t(model, cfg, d, t, dev)
@@ -469,7 +471,9 @@ def test_cora_size_training_step_matches_reference(dev):
             idx = gu.grad_sample_index(cfg, f"{pre}.{k}", got.size)
             _close(got[idx], gold[f"gsamp_{pre}.{k}"], 2e-6, 2e-4, f"grad {pre}.{k} (sampled entries)")
             nrm = float(gold[f"gnorm_{pre}.{k}"][0])
-            assert abs(np.linalg.norm(got) - nrm) <= 2e-5 * nrm + 1e-9, f"grad {pre}.{k}: norm {np.linalg.norm(got):.6e} vs {nrm:.6e}"
+            # (absolute floor 1e-8: the time-embedding gradients are sums over all nodes that cancel to ~4e-5, and their last digits
+            # follow the summation order)
+            assert abs(np.linalg.norm(got) - nrm) <= 2e-5 * nrm + 1e-8, f"grad {pre}.{k}: norm {np.linalg.norm(got):.6e} vs {nrm:.6e}"
             checked += 1
     assert checked == sum(1 for _ in model.graph_encoder.parameters())
     model = model.eval()
@@ -478,7 +482,10 @@ def test_cora_size_training_step_matches_reference(dev):
                                                               u=torch.from_numpy(gu.train_uniforms(cfg, "E", step)).to(dev))
     model._noise_X = lambda x0, ab, seed, step, u=None: nX(x0, ab, seed, step,
                                                            u=torch.from_numpy(gu.train_uniforms(cfg, "X", step)).to(dev))
-    v = model.val_step(d["X3"], d["E1h"], d["Y"], d["bsrc"], d["bdst"], d["bE"])
+    if cfg["variant"] == "Sync":
+        v = model.val_step(d["X3"], d["E1h"], d["Y"], d["bsrc"], d["bdst"], d["bE"])
+    else:
+        v = model.val_step(d["X3"], d["E1h"], d["Y"], d["X2"], d["bsrc"], d["bdst"], d["bE"])
     for got, ref, what in zip(v, gold["val_step"], ("denoise_match_E", "denoise_match_X", "log_p_0_E", "log_p_0_X")):
         assert abs(got - ref) <= 1e-5 * abs(ref) + 1e-9, (what, got, ref)
 

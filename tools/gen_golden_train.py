@@ -140,38 +140,57 @@ def run_case(name, diffusion):
 
 
 def run_large_case(name, diffusion):
-    """A BASELINE.json-sized training step (gu.LARGE_CASES, Sync): the reference's log_p_t at every t, autograd backward at
-    t = T-1 and val_step at N=2708, F=1433 with the yaml's hidden sizes and batch size (configs/cora/train_Sync.yaml:42).
+    """A BASELINE.json-sized training step (gu.LARGE_CASES): the reference's log_p_t at every t, autograd backward at the last
+    interior t and val_step at N=2708, F=1433 with the yaml's hidden sizes and batch size (configs/cora/train_{Sync,Async}.yaml).
     Stored: the losses, the validation terms, and of every parameter gradient its L2 norm and the values at 2048 fixed
     positions (golden_util.grad_sample_index) -- the full gradients are 80 MB."""
     cfg = dict(gu.LARGE_CASES[name])
     Ctx.cfg = cfg
     N, F = cfg["N"], cfg["F"]
+    sync = cfg["variant"] == "Sync"
     model = build(cfg, diffusion)
     model.train()
     x0, Y, E0 = gu.real_graph(cfg)
     X3 = F_.one_hot(torch.from_numpy(x0.T.astype(np.int64)), 2).float()
+    X2 = torch.transpose(X3, 0, 1).reshape(N, -1)
     E1h = F_.one_hot(torch.from_numpy(E0), 2).float()
     Yt = torch.from_numpy(Y)
     bdst, bsrc = (torch.from_numpy(a) for a in gu.train_batch(cfg, B=gu.LARGE_TRAIN_BATCH))
     bE = E1h[bdst, bsrc]
     out = {}
-    orig = model.apply_noise
+    if sync:
+        orig = model.apply_noise
 
-    def apply_noise(X, E, t=None):
-        Ctx.t_E = Ctx.t_X = int(t.item())
-        return orig(X, E, t)
-    model.apply_noise = apply_noise
+        def apply_noise(X, E, t=None):
+            Ctx.t_E = Ctx.t_X = int(t.item())
+            return orig(X, E, t)
+        model.apply_noise = apply_noise
+        T_list = list(range(cfg["T"] + 1))
+    else:
+        oX, oE = model.apply_noise_X, model.apply_noise_E
+
+        def apply_noise_X(X, t=None):
+            Ctx.t_X = int(t.item())
+            return oX(X, t)
+
+        def apply_noise_E(E, t=None):
+            Ctx.t_E = int(t.item())
+            return oE(E, t)
+        model.apply_noise_X, model.apply_noise_E = apply_noise_X, apply_noise_E
+        T_list = list(range(min(cfg["T_X"], cfg["T_E"]) + 1))
     saved = torch.Tensor.multinomial
     torch.Tensor.multinomial = _shim_multinomial
     try:
         losses = []
-        T = cfg["T"]
-        for t in range(T + 1):
+        for t in T_list:
             model.zero_grad()
-            lX, lE = model.log_p_t(X3, E1h, Yt, bsrc, bdst, bE, torch.LongTensor([t]))
+            tt = torch.LongTensor([t])
+            if sync:
+                lX, lE = model.log_p_t(X3, E1h, Yt, bsrc, bdst, bE, tt)
+            else:
+                lX, lE = model.log_p_t(X3, E1h, Yt, X2, bsrc, bdst, bE, tt, tt)
             losses.append([lX.item(), lE.item()])
-            if t == T - 1:
+            if t == T_list[-2]:
                 (lX + lE).backward()
                 out["grad_t"] = np.array([t], np.int32)
                 for pre, mod in (("X", model.graph_encoder.pred_X), ("E", model.graph_encoder.pred_E)):
@@ -181,7 +200,7 @@ def run_large_case(name, diffusion):
                         out[f"gsamp_{pre}.{k}"] = g[gu.grad_sample_index(cfg, f"{pre}.{k}", g.size)].astype(np.float32)
         out["losses"] = np.array(losses, np.float64)
         model.eval()
-        v = model.val_step(X3, E1h, Yt, bsrc, bdst, bE)
+        v = model.val_step(X3, E1h, Yt, bsrc, bdst, bE) if sync else model.val_step(X3, E1h, Yt, X2, bsrc, bdst, bE)
         out["val_step"] = np.array(v, np.float64)
     finally:
         torch.Tensor.multinomial = saved
