@@ -1,3 +1,5 @@
+# tools/rehearse_world.sh (GPU box, via gpurun): the sharded GPU tests, then one rank's share of a G-rank step for G = 2, 4, 8 and both tower
+# splits (bench.py --rehearse-world, collectives replaced by no-ops), the 1-rank RCCL path and the other --workload lines -> gpurun_out/r3_*
 set -e
 cd $GRAFT_REPO_ROOT
 timeout -k 10 400 python -u -m pytest tests/test_gpu_sharded.py "tests/test_gpu_parity.py::test_eight_rank_shards_reproduce_single_gpu_step_at_amazon_computer_size" -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/r3_tests_c.log 2>&1 || { tail -30 gpurun_out/r3_tests_c.log; exit 1; }

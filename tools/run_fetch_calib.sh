@@ -1,3 +1,4 @@
+# tools/run_fetch_calib.sh (GPU box, via gpurun): tools/micro/fetch_calib under rocprofv3 --pmc FETCH_SIZE (what the counter reports per access shape)
 set -e
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/fetch_calib; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Print the kernel timeline of the last profiled step from a rocprofv3 --kernel-trace sqlite database
-(usage: python tools/trace_step.py <results.db> [marker-kernel-substring, default k_row_degree])."""
+(usage: python tools/trace_step.py <results.db> [marker-kernel-substring, default k_row_degree] [marker launches per step, default 1])."""
 import sqlite3, sys
 db = sys.argv[1]
 marker = sys.argv[2] if len(sys.argv) > 2 else "k_row_degree"
 rows = list(sqlite3.connect(db).execute("select name,start,end,grid_x,workgroup_x from kernels order by start"))
 idx = [i for i, r in enumerate(rows) if marker in r[0]]
-s, e = idx[-2], idx[-1]
+per = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+s, e = idx[-1 - per], idx[-1]
 t0, prev = rows[s][1], None
 tot = {}
 for r in rows[s:e]:
